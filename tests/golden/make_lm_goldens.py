@@ -1,0 +1,132 @@
+"""Generate the committed LM golden vectors.  Runs ONLY in the build container.
+
+It imports the *reference* torch model from /root/reference (read-only, never copied), loads a
+seeded synthetic checkpoint into it and uses its unmodified teacher-forced ``RQTransformer.forward``
+(modeling/model/rq_transformer.py:401-479) to pin our CPU oracle (oracle/lm_oracle.py):
+
+1. oracle.teacher_forced(grid) logits == reference forward logits (fp32, tight tolerance);
+2. the oracle's greedy, KV-cached generation is self-consistent with the reference forward:
+   for every generated position s, argmax(reference token_logits[s]) == grid[0, s+1] and
+   argmax(reference codebook_logits[s]) == grid[1:, s+1]  (SURVEY.md §8c);
+3. the byte-level tokenizer ids == the ids of the tokenizer produced by the reference's own
+   data_pipeline/scripts/create_bytelevel_init.py.
+
+What is committed (tests/golden/lm_*.npz) is data only: seeds, prompt text/ids, generated id grids,
+a few reference logits rows, top-2 margins and the weight fingerprint.
+
+Usage:  PYTHONPATH=/root/reference:/root/repo TORCH_COMPILE_DISABLE=1 PYTHONDONTWRITEBYTECODE=1 \
+        python tests/golden/make_lm_goldens.py
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("TORCH_COMPILE_DISABLE", "1")
+
+from oracle.lm_oracle import LMOracle, OracleLMConfig  # noqa: E402
+from smoltts_amd.prompt import PromptEncoder  # noqa: E402
+from smoltts_amd.synthetic import named_config, state_fingerprint, synthetic_lm_state  # noqa: E402
+from smoltts_amd.tokenizer import load_tokenizer  # noqa: E402
+
+REF = Path("/root/reference")
+OUT = Path(__file__).resolve().parent
+
+CASES = [
+    # name, config, seed, frames, [(text, voice)]
+    ("tiny", "tiny", 7, 12, [("Hello world!", "heart"), ("The quick brown fox.", "sky")]),
+    ("70m", "smoltts_byte_70m", 0, 16, [("Hello world!", "heart")]),
+    ("150m", "smoltts_byte_150m", 0, 16, [("Hello world!", "heart"), ("Streaming speech on MI355X, 12.5 frames per second.", "nova")]),
+]
+
+
+def build_reference(cfg, state, tokdir):
+    sys.path.insert(0, str(REF))
+    from modeling.model.rq_transformer import RQTransformer, RQTransformerModelArgs as RefArgs
+    from transformers import AutoTokenizer
+
+    ref_cfg = RefArgs(**{k: v for k, v in cfg.__dict__.items()})
+    tok = AutoTokenizer.from_pretrained(tokdir)
+    model = RQTransformer(ref_cfg, tokenizer=tok)
+    missing = model.load_state_dict(state, strict=True)
+    print("reference load_state_dict:", missing)
+    model.eval()
+    return model, tok
+
+
+def main():
+    tokdir = tempfile.mkdtemp(prefix="smoltts_tok_")
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    subprocess.run(
+        [sys.executable, str(REF / "data_pipeline/scripts/create_bytelevel_init.py"), "--out-dir", tokdir],
+        check=True, env=env, stdout=subprocess.DEVNULL,
+    )
+    ours = load_tokenizer()
+    from tokenizers import Tokenizer
+
+    ref_tok_json = Tokenizer.from_file(os.path.join(tokdir, "tokenizer.json"))
+    tok_samples = ["Hello world!", "<|im_start|>system\n<|speaker:3|><|im_end|>", "a user asked the system assistant",
+                   "café 你好 <|semantic:12|><|semantic:2047|>", "<|im_start|>assistant\n"]
+    tok_ids = []
+    for s in tok_samples:
+        a = ref_tok_json.encode(s, add_special_tokens=True).ids
+        assert a == ours.encode(s).ids, s
+        tok_ids.append(a)
+    special = {t: ref_tok_json.token_to_id(t) for t in
+               ["system", "user", "assistant", "<|im_start|>", "<|im_end|>", "<|speaker:0|>", "<|speaker:48|>",
+                "<|semantic:0|>", "<|semantic:2047|>", "<|pad|>", "<|semantic|>"]}
+    (OUT / "tokenizer_golden.json").write_text(json.dumps(
+        {"samples": tok_samples, "ids": tok_ids, "special": special, "vocab_size": ref_tok_json.get_vocab_size()},
+        indent=1, ensure_ascii=True))
+    print("tokenizer pinned:", special)
+
+    for name, cfgname, seed, frames, prompts in CASES:
+        cfg = named_config(cfgname)
+        state = synthetic_lm_state(cfg, seed=seed)
+        fp = state_fingerprint(state)
+        ref, _ = build_reference(cfg, state, tokdir)
+        ocfg = OracleLMConfig.from_dict(cfg.__dict__)
+        oracle = LMOracle(ocfg, state, embed_mask="torch", rope_bf16=True)
+        pe = PromptEncoder(ours, 320, cfg.num_codebooks, cfg.duplicate_code_0)
+        grids = [torch.from_numpy(pe.build_prompt(t, v)).long() for t, v in prompts]
+        logs = oracle.generate(grids, max_frames=frames, stop_on_eos=False)
+        save = {"seed": seed, "fingerprint": fp, "frames": frames, "config_name": cfgname,
+                "texts": np.array([t for t, _ in prompts]), "voices": np.array([v for _, v in prompts])}
+        for b, (g, log) in enumerate(zip(grids, logs)):
+            gen = log.as_tensor()  # 9,F
+            full = torch.cat([g, gen], dim=1)  # 9, T+F
+            with torch.no_grad():
+                out = ref(full[None])
+            tl, cl = out.token_logits[0], out.codebook_logits[0]  # (S,V), (S,n,2048)
+            T = g.shape[1]
+            # (1) oracle teacher-forced == reference forward
+            otl, ocl = oracle.teacher_forced(full)
+            e1 = float((otl - tl).abs().max()); e2 = float((ocl - cl).abs().max())
+            print(f"[{name}/{b}] teacher-forced max|diff| token {e1:.3e} codebook {e2:.3e}")
+            assert e1 < 2e-4 and e2 < 2e-5, (e1, e2)
+            # (2) self-consistency of the generated ids under the reference forward
+            for f in range(frames):
+                s = T - 1 + f
+                assert int(tl[s].argmax()) == int(gen[0, f]), (name, b, f, "slow")
+                assert cl[s].argmax(-1).tolist() == gen[1:, f].tolist(), (name, b, f, "fast")
+            print(f"[{name}/{b}] {frames} frames self-consistent; min top-2 margin {log.min_margin:.3e}")
+            save[f"prompt_{b}"] = g.numpy().astype(np.int32)
+            save[f"grid_{b}"] = gen.numpy().astype(np.int32)
+            save[f"min_margin_{b}"] = log.min_margin
+            rows = [T - 1, T, T + frames - 2]
+            save[f"ref_rows_{b}"] = np.array(rows)
+            save[f"ref_token_logits_{b}"] = tl[rows].numpy().astype(np.float32)
+            save[f"ref_codebook_logits_{b}"] = cl[rows][:, :, :64].numpy().astype(np.float32)
+        np.savez_compressed(OUT / f"lm_{name}.npz", **save)
+        print("wrote", OUT / f"lm_{name}.npz")
+
+
+if __name__ == "__main__":
+    main()
