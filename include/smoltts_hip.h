@@ -1,0 +1,279 @@
+/*
+ * libsmoltts_hip.so — C ABI of the MI355X (gfx950) DualAR + Mimi decode hot path.
+ *
+ * The reference (EndlessReform/smoltts) has no FFI: its hot path is Python objects calling MLX
+ * ops.  The seams this ABI replaces are (paths relative to the reference tree):
+ *
+ *   smoltts_lm_prefill / smoltts_lm_decode     <- RQTransformer.forward_generate + the 8x
+ *       forward_generate_fast loop + argmax, i.e. one SingleBatchGenerator.__next__
+ *       (mlx_inference/src/smoltts_mlx/lm/rq_transformer.py:173-220, lm/generate.py:59-171),
+ *       generalised from batch 1 to B independent utterance slots
+ *   smoltts_mimi_decode / smoltts_mimi_decode_step <- MimiModel.decode / decode_step
+ *       (mlx_inference/src/smoltts_mlx/codec/mimi.py:88-104)
+ *   smoltts_k_*                                 <- single operators (RMSNorm+Linear, RoPE, SDPA,
+ *       SwiGLU, embed, argmax, conv-as-GEMM, LayerNorm) exported for unit parity tests
+ *
+ * Conventions: plain C types only; every pointer named *_dev is a device (HBM) address owned by
+ * the caller (e.g. torch.Tensor.data_ptr()); the library never allocates or frees caller memory
+ * and keeps all per-session state inside the caller-allocated slab, so one engine can serve many
+ * sessions and one host thread per stream can drive it.  `stream` is a hipStream_t passed as
+ * void* (NULL = default stream).  Every function returns 0 on success or a negative SMOLTTS_E_*
+ * code; smoltts_last_error() returns a thread-local message.  No exceptions cross the boundary.
+ */
+#ifndef SMOLTTS_HIP_H
+#define SMOLTTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMOLTTS_ABI_VERSION 1
+
+enum {
+  SMOLTTS_OK = 0,
+  SMOLTTS_E_INVALID = -1,   /* bad argument / unsupported shape */
+  SMOLTTS_E_HIP = -2,       /* a HIP runtime call failed */
+  SMOLTTS_E_STATE = -3,     /* call sequence error (e.g. decode before prefill) */
+  SMOLTTS_E_CAPACITY = -4   /* slab / sequence / batch capacity exceeded */
+};
+
+const char* smoltts_last_error(void);
+int smoltts_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight tile format ("T16x32"): a row-major [N][K] matrix is stored as tiles of 16 rows x 32
+ * columns, tile (nt, kc) at element offset (nt * K/32 + kc) * 512, inside a tile in fp32-MFMA
+ * fragment order: lane l = 16*q + r (r = row in tile, q = 0..3) owns the 8 consecutive
+ * elements [r][8q .. 8q+8).  bf16 tiles: 16 bytes per lane, lane-linear (one 1 KiB wave load).
+ * fp32 tiles: two 1 KiB halves, half h holds elements [r][8q+4h .. 8q+4h+4) of every lane.
+ * N is padded to a multiple of 16 with zero rows; K must be a multiple of 32.
+ * smoltts_amd/packing.py produces it.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Byte offsets into the LM weight arena. */
+typedef struct SmolttsBlockWeights {
+  uint64_t attn_norm;   /* fp32 [dim] */
+  uint64_t wqkv;        /* bf16 T16x32 [(H+2KV)*64][dim], rows q|k|v */
+  uint64_t wo;          /* bf16 T16x32 [dim][dim] */
+  uint64_t ffn_norm;    /* fp32 [dim] */
+  uint64_t w13;         /* bf16 T16x32 [2*inter][dim], row 2i = w1 row i, row 2i+1 = w3 row i */
+  uint64_t w2;          /* bf16 T16x32 [dim][inter] */
+} SmolttsBlockWeights;
+
+#define SMOLTTS_MAX_LAYERS 64
+#define SMOLTTS_MAX_FAST_LAYERS 16
+
+typedef struct SmolttsLMConfig {
+  int32_t dim, n_layer, n_head, n_kv_head, inter;
+  int32_t fast_dim, n_fast_layer, fast_n_head, fast_n_kv_head, fast_inter;
+  int32_t vocab_size, codebook_size, num_codebooks;
+  int32_t n_fast;             /* fast steps per frame = num_codebooks - (duplicate_code_0 ? 0 : 1) */
+  int32_t duplicate_code_0;
+  int32_t depthwise_wte;
+  int32_t has_fast_project_in;/* Linear(dim, fast_dim) with bias between slow hidden and fast input */
+  int32_t embed_mask_mode;    /* 0: zero codebook-embedding sum where code0 == 0 (torch);
+                                 1: zero it where the text token is outside [semantic_start, semantic_end] (MLX) */
+  int32_t semantic_start_id, semantic_end_id, im_end_id;
+  int32_t max_seq_len;        /* rows of the slow RoPE table */
+  float norm_eps;
+} SmolttsLMConfig;
+
+typedef struct SmolttsLMWeights {
+  uint64_t text_emb;      /* bf16 row-major [vocab][dim] */
+  uint64_t codebook_emb;  /* bf16 row-major [codebook_size*num_codebooks][dim] */
+  uint64_t fast_emb;      /* bf16 row-major [fast rows][fast_dim] */
+  uint64_t norm;          /* fp32 [dim] */
+  uint64_t head;          /* bf16 T16x32 [vocab][dim] (tied: same values as text_emb) */
+  uint64_t fast_norm;     /* fp32 [fast_dim] */
+  uint64_t fast_head;     /* bf16 T16x32 [n_fast*codebook_size][fast_dim]; step i uses rows
+                             [i*codebook_size, (i+1)*codebook_size) (all steps share rows [0, cs)
+                             when the checkpoint has no depthwise output) */
+  uint64_t fast_head_step_stride; /* rows between consecutive steps: codebook_size or 0 */
+  uint64_t fast_proj_w;   /* bf16 T16x32 [fast_dim][dim], only if has_fast_project_in */
+  uint64_t fast_proj_b;   /* fp32 [fast_dim] */
+  uint64_t rope;          /* fp32 [max_seq_len][32][2] (cos, sin) */
+  uint64_t fast_rope;     /* fp32 [n_fast][32][2] */
+  SmolttsBlockWeights layers[SMOLTTS_MAX_LAYERS];
+  SmolttsBlockWeights fast_layers[SMOLTTS_MAX_FAST_LAYERS];
+} SmolttsLMWeights;
+
+typedef struct SmolttsEngine SmolttsEngine;
+typedef struct SmolttsSession SmolttsSession;
+
+/* Engine = immutable model (config + weight arena pointers). The arena must outlive the engine. */
+int smoltts_engine_create(const SmolttsLMConfig* cfg, const SmolttsLMWeights* offsets,
+                          const void* arena_dev, size_t arena_bytes, SmolttsEngine** out);
+void smoltts_engine_destroy(SmolttsEngine* e);
+
+/* Session = B utterance slots with KV caches, all inside one caller-allocated device slab.
+ * max_rows bounds the prompt rows one smoltts_lm_prefill call may carry; max_frames bounds the
+ * frames a slot may emit (output ring). */
+size_t smoltts_session_slab_bytes(const SmolttsEngine* e, int32_t max_batch, int32_t max_seq,
+                                  int32_t max_rows, int32_t max_frames);
+int smoltts_session_create(SmolttsEngine* e, void* slab_dev, size_t slab_bytes, int32_t max_batch,
+                           int32_t max_seq, int32_t max_rows, int32_t max_frames,
+                           SmolttsSession** out);
+void smoltts_session_destroy(SmolttsSession* s);
+
+/* Prefill: run the slow transformer over n_rows prompt tokens (packed over utterances) and emit
+ * frame 0 of every listed slot (slow head + n_fast depth steps, greedy).
+ *   grid_dev      int32 [n_rows][1 + n_fast]   prompt columns (text id, code rows)
+ *   row_slot_dev  int32 [n_rows]               slot of each row
+ *   row_pos_dev   int32 [n_rows]               position of each row inside its utterance (0-based)
+ *   slots_host    int32 [n_slots]              slots being (re)started (host memory)
+ *   last_row_host int32 [n_slots]              index of each slot's last prompt row (host memory)
+ * Slot state (position, frame counter, done flag) is reset for the listed slots; other slots are
+ * untouched.  Asynchronous on `stream`. */
+int smoltts_lm_prefill(SmolttsSession* s, const int32_t* grid_dev, const int32_t* row_slot_dev,
+                       const int32_t* row_pos_dev, int32_t n_rows, const int32_t* slots_host,
+                       const int32_t* last_row_host, int32_t n_slots, int32_t stop_on_eos,
+                       void* stream);
+
+/* Decode n_frames further frames for every slot of the session: each frame feeds the previous
+ * column back (slow step at the slot's next position), then slow head + n_fast depth steps, all
+ * greedy and on device; the frame loop is a captured hipGraph replayed n_frames times.  Slots that
+ * are done (emitted <|im_end|> with stop_on_eos, or reached max_frames) are frozen. */
+int smoltts_lm_decode(SmolttsSession* s, int32_t n_frames, void* stream);
+
+/* Device pointers to the session's results (valid for the session's lifetime):
+ *   codes      int32 [max_batch][max_frames][1 + n_fast]   emitted columns (slow id, codes)
+ *   n_frames   int32 [max_batch]                            frames emitted so far per slot
+ *   done       int32 [max_batch]
+ *   margin     float [max_batch]   smallest top-1/top-2 logit gap seen by the slot's argmaxes */
+int smoltts_session_outputs(SmolttsSession* s, int32_t** codes_dev, int32_t** n_frames_dev,
+                            int32_t** done_dev, float** margin_dev);
+
+/* ------------------------------------------------------------------------------ Mimi decoder */
+#define SMOLTTS_MIMI_MAX_LAYERS 16
+
+typedef struct SmolttsMimiLayerWeights {
+  uint64_t ln1_w, ln1_b;     /* fp32 [512] */
+  uint64_t wqkv;             /* fp32 T16x32 [1536][512]; q and k rows permuted per head so that the
+                                half-split RoPE pair (j, j+32) sits at rows (2j, 2j+1) */
+  uint64_t wo;               /* fp32 T16x32 [512][512] */
+  uint64_t ls1;              /* fp32 [512] attention layer scale */
+  uint64_t ln2_w, ln2_b;
+  uint64_t fc1;              /* fp32 T16x32 [2048][512] */
+  uint64_t fc2;              /* fp32 T16x32 [512][2048] */
+  uint64_t ls2;
+} SmolttsMimiLayerWeights;
+
+typedef struct SmolttsMimiConv {
+  uint64_t w;                /* fp32 T16x32 [N][K] GEMM form, see DESIGN.md "convolutions as GEMMs" */
+  uint64_t b;                /* fp32 [N] (bias repeated per phase for transposed convs) */
+  int32_t cin, cout, k, stride, transposed;
+} SmolttsMimiConv;
+
+typedef struct SmolttsMimiConfig {
+  int32_t num_codebooks;     /* codebooks consumed per frame (8) */
+  int32_t n_layers;          /* decoder transformer layers (8) */
+  int32_t window;            /* attention window in positions; 0 = unbounded (reference MLX behaviour) */
+  int32_t max_positions;     /* rows of the RoPE table / KV capacity per slot (2 per frame) */
+} SmolttsMimiConfig;
+
+typedef struct SmolttsMimiWeights {
+  uint64_t rvq_table;        /* fp32 [num_codebooks][2048][512]: codebook rows already projected by
+                                their group's output_proj */
+  uint64_t upsample_w;       /* fp32 [4][512] depthwise ConvTranspose taps, tap-major */
+  uint64_t rope;             /* fp32 [max_positions][32][2] */
+  SmolttsMimiLayerWeights layers[SMOLTTS_MIMI_MAX_LAYERS];
+  SmolttsMimiConv convs[14]; /* SEANet decoder in execution order: conv0, then per ratio
+                                (convtr, res.conv3, res.conv1) x4, then the final conv (14 in all) */
+} SmolttsMimiWeights;
+
+typedef struct SmolttsMimi SmolttsMimi;
+typedef struct SmolttsMimiSession SmolttsMimiSession;
+
+int smoltts_mimi_create(const SmolttsMimiConfig* cfg, const SmolttsMimiWeights* offsets,
+                        const void* arena_dev, size_t arena_bytes, SmolttsMimi** out);
+void smoltts_mimi_destroy(SmolttsMimi* m);
+
+/* Session: per-slot streaming state (upsample carry, transformer KV, conv halos) + scratch for
+ * up to max_chunk_frames frames per slot per call. */
+size_t smoltts_mimi_slab_bytes(const SmolttsMimi* m, int32_t max_batch, int32_t max_chunk_frames);
+int smoltts_mimi_session_create(SmolttsMimi* m, void* slab_dev, size_t slab_bytes, int32_t max_batch,
+                                int32_t max_chunk_frames, SmolttsMimiSession** out);
+void smoltts_mimi_session_destroy(SmolttsMimiSession* s);
+/* Forget all streaming state of the session (start new utterances in every slot). */
+int smoltts_mimi_reset(SmolttsMimiSession* s, void* stream);
+
+/* Decode n_frames new frames for slots [0, batch): codes_dev int32 [batch][codes_stride] where
+ * frame f of slot b starts at codes_dev[b*codes_stride + f*frame_stride + code_offset] and holds
+ * num_codebooks ints; pcm_dev float [batch][pcm_stride] receives 1920*n_frames samples per slot.
+ * Streaming state is carried between calls, so decoding F frames in chunks equals decoding them
+ * at once (== MimiModel.decode of the whole code grid). */
+int smoltts_mimi_decode_chunk(SmolttsMimiSession* s, const int32_t* codes_dev, int64_t codes_stride,
+                              int32_t frame_stride, int32_t code_offset, int32_t batch,
+                              int32_t n_frames, float* pcm_dev, int64_t pcm_stride, void* stream);
+
+/* --------------------------------------------------------------- operator-level test entry points */
+enum {  /* prologue applied to the activation operand */
+  SMOLTTS_PRO_NONE = 0,
+  SMOLTTS_PRO_RMSNORM = 1,  /* x * rsqrt(mean(x^2)+eps) * gamma */
+  SMOLTTS_PRO_ELU = 2
+};
+enum {  /* epilogue */
+  SMOLTTS_EPI_STORE = 0,        /* out = acc (+ bias) */
+  SMOLTTS_EPI_RESID = 1,        /* out = resid + acc (+ bias) */
+  SMOLTTS_EPI_SWIGLU = 2,       /* rows interleaved (gate, up): out[n/2] = silu(gate) * up */
+  SMOLTTS_EPI_GELU = 3,         /* out = gelu_erf(acc) */
+  SMOLTTS_EPI_SCALE_RESID = 4,  /* out = resid + scale[n] * acc */
+  SMOLTTS_EPI_QKV_ROPE = 5      /* interleaved RoPE on q,k; q -> out, k/v -> caches */
+};
+
+typedef struct SmolttsGemmArgs {
+  const void* w_dev;          /* T16x32 tiles */
+  int32_t w_is_fp32;          /* 0: bf16, 1: fp32 */
+  const float* x_dev;         /* activations; row m at x + (m / rows_per_batch) * x_bstride
+                                 + (m % rows_per_batch) * ldx   (rows_per_batch 0 => m * ldx) */
+  int64_t ldx, x_bstride;
+  int32_t rows_per_batch;
+  int32_t M, N, K;
+  int32_t prologue, epilogue;
+  const float* gamma_dev;     /* RMSNorm weight [K] */
+  float eps;
+  const float* bias_dev;      /* [N] or NULL */
+  const float* scale_dev;     /* [N], EPI_SCALE_RESID */
+  const float* resid_dev;     /* row m at resid + (m / rpb) * r_bstride + (m % rpb) * ldr;
+                                 ldr == 0 => same addressing as out */
+  int64_t ldr, r_bstride;
+  float* out_dev;             /* row m at out + (m / rows_per_batch) * o_bstride + (m % rpb) * ldo */
+  int64_t ldo, o_bstride;
+  /* EPI_QKV_ROPE */
+  const float* rope_dev;      /* [pos][32][2] */
+  const int32_t* row_pos_dev; /* [M] */
+  const int32_t* row_slot_dev;/* [M] */
+  float* k_cache_dev;         /* [slots][n_kv][cache_len][64] */
+  float* v_cache_dev;
+  int32_t n_q_heads, n_kv_heads, cache_len;
+} SmolttsGemmArgs;
+
+int smoltts_k_gemm(const SmolttsGemmArgs* a, void* stream);
+
+/* GQA attention of one query row per (row, kv head) over the slot's cache prefix:
+ * keys [max(0, pos+1-window), pos]; q_dev/out_dev [n_rows][n_q_heads*64]. */
+int smoltts_k_attention(const float* q_dev, const float* k_cache_dev, const float* v_cache_dev,
+                        const int32_t* row_pos_dev, const int32_t* row_slot_dev, int32_t n_rows,
+                        int32_t n_q_heads, int32_t n_kv_heads, int32_t cache_len, int32_t window,
+                        float* out_dev, void* stream);
+
+/* x[r] = E_text[cols[r][0]] + keep * sum_k E_cb[cols[r][1+k] + k*codebook_size] */
+int smoltts_k_embed(const int32_t* cols_dev, int32_t n_rows, int32_t n_code_rows,
+                    const void* text_emb_dev, const void* cb_emb_dev, int32_t dim,
+                    int32_t codebook_size, int32_t cb_first_offset, int32_t mask_mode,
+                    int32_t sem_start, int32_t sem_end, float* x_dev, void* stream);
+
+/* ids[r] = first index of the row maximum; margin[r] = min(margin[r], top1 - top2). */
+int smoltts_k_argmax(const float* logits_dev, int32_t n_rows, int32_t n_cols, int64_t ld,
+                     int32_t* ids_dev, int32_t ids_stride, float* margin_dev, void* stream);
+
+int smoltts_k_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, int32_t n_rows,
+                        int32_t dim, float eps, float* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMOLTTS_HIP_H */

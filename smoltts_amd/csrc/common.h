@@ -1,0 +1,62 @@
+// Shared helpers for the gfx950 kernels and the C-ABI glue.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/smoltts_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace smoltts {
+
+void set_error(const char* fmt, ...);
+
+#define ST_CHECK_HIP(expr)                                                                \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      smoltts::set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,               \
+                         hipGetErrorString(_e));                                          \
+      return SMOLTTS_E_HIP;                                                               \
+    }                                                                                     \
+  } while (0)
+
+#define ST_REQUIRE(cond, code, ...)                                                       \
+  do {                                                                                    \
+    if (!(cond)) {                                                                        \
+      smoltts::set_error(__VA_ARGS__);                                                    \
+      return (code);                                                                      \
+    }                                                                                     \
+  } while (0)
+
+#define ST_TRY(expr)                                                                      \
+  do {                                                                                    \
+    int _r = (expr);                                                                      \
+    if (_r != SMOLTTS_OK) return _r;                                                      \
+  } while (0)
+
+// ---- device helpers
+__device__ __forceinline__ float bf16_lo(uint32_t dw) { return __uint_as_float(dw << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t dw) { return __uint_as_float(dw & 0xffff0000u); }
+
+// Launchers implemented across the .hip files (all asynchronous on `stream`).
+int launch_gemm(const SmolttsGemmArgs& a, hipStream_t stream);
+int launch_attention(const float* q, const float* kc, const float* vc, const int32_t* row_pos,
+                     const int32_t* row_slot, int n_rows, int n_q_heads, int n_kv_heads,
+                     int cache_len, int window, float* out, hipStream_t stream);
+int launch_embed(const int32_t* cols, int n_rows, int n_code_rows, const void* text_emb,
+                 const void* cb_emb, int dim, int codebook_size, int cb_first_offset, int mask_mode,
+                 int sem_start, int sem_end, int text_rows, int cb_rows, float* x, hipStream_t stream);
+// argmax over each row; writes ids[r*ids_stride]; optionally (emb != nullptr) gathers
+// emb[(id + emb_row_offset)] (bf16 row-major, `dim` wide) into xnext[r].
+int launch_argmax(const float* logits, int n_rows, int n_cols, int64_t ld, int32_t* ids,
+                  int ids_stride, float* margin, const int32_t* margin_mask, const void* emb,
+                  int emb_row_offset, int dim, float* xnext, hipStream_t stream);
+int launch_layernorm(const float* x, const float* w, const float* b, int n_rows, int dim, float eps,
+                     float* out, hipStream_t stream);
+int launch_gather_rows(const float* src, const int32_t* idx, int n, int dim, float* dst,
+                       hipStream_t stream);
+
+}  // namespace smoltts

@@ -1,0 +1,314 @@
+// Skinny GEMM on the fp32-input matrix cores:  out[M,N] = epi( pro(X)[M,K] . W[N,K]^T ).
+//
+// This one kernel family carries every dense contraction of the hot path (reference:
+// nn.Linear / F.linear in modeling/model/rq_transformer.py:253,545,570,582,598 and the Mimi
+// Linear/Conv1d/ConvTranspose1d layers of mlx_inference/.../codec/{transformer,conv,seanet}.py).
+//
+// Design (MI355X):
+//  * v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate, a k-ordered fma chain, so
+//    results are reproducible and within fp32 rounding of the CPU oracle (token-id parity).
+//    The weight tile is the A operand (16 output columns x 4 k), the activations are B
+//    (4 k x 16 rows): one MFMA retires 64 weights for 16 rows, so for batch <= 32 the kernel is
+//    bound by streaming the weights, not by the matrix pipe.
+//  * Weights are pre-tiled on the host in fragment order ("T16x32", include/smoltts_hip.h): one
+//    wave-wide 16-byte load = one contiguous 1 KiB piece; each weight byte is read from HBM once.
+//  * Workgroup = one 16-column tile x MT 16-row tiles x all of K; the waves of the workgroup split
+//    K chunk-wise (chunk = 32 k) and keep U chunks of loads in flight each; partial tiles are
+//    summed through LDS in fixed wave order (deterministic, no atomics).
+//  * Prologues/epilogues fuse RMSNorm (the row rsqrt is applied after the contraction), ELU,
+//    bias, residual, SwiGLU, GELU, layer scale and RoPE + q/KV-cache scatter into the same launch.
+#include "common.h"
+
+namespace smoltts {
+
+struct GemmDev {
+  const char* w;
+  const float* x;
+  long ldx, x_bstride;
+  int rows_per_batch;
+  int M, N, K;
+  const float* gamma;
+  float eps;
+  const float* bias;
+  const float* scale;
+  const float* resid;
+  float* out;
+  long ldo, o_bstride;
+  long ldr, r_bstride;
+  const float* rope;
+  const int* row_pos;
+  const int* row_slot;
+  float* kc;
+  float* vc;
+  int n_q_heads, n_kv_heads, cache_len;
+};
+
+__device__ __forceinline__ long row_off(int m, int rpb, long ld, long bstride) {
+  if (rpb <= 0) return (long)m * ld;
+  int b = m / rpb;
+  return (long)b * bstride + (long)(m - b * rpb) * ld;
+}
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+__device__ __forceinline__ float silu1(float x) { return x / (1.f + expf(-x)); }
+__device__ __forceinline__ float gelu1(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+template <bool WF32, int MT, int U, int PRO, int EPI>
+__global__ __launch_bounds__(MT >= 4 ? 512 : 1024) void gemm_kernel(GemmDev p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nwaves = blockDim.x >> 6;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int nt = blockIdx.x, mg = blockIdx.y;
+  const int nchunks = p.K >> 5;
+  constexpr int WBYTES = WF32 ? 2048 : 1024;
+
+  f32x4 acc[MT];
+  float ss[MT];
+  const float* xrow[MT];
+  bool xv[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ss[mt] = 0.f;
+    const int m = (mg * MT + mt) * 16 + r;
+    xv[mt] = m < p.M;
+    xrow[mt] = p.x + (xv[mt] ? row_off(m, p.rows_per_batch, p.ldx, p.x_bstride) : 0);
+  }
+  const char* wt = p.w + (size_t)nt * nchunks * WBYTES + lane * 16;
+
+  for (int c0 = wave; c0 < nchunks; c0 += nwaves * U) {
+    uint4 wraw[U][WF32 ? 2 : 1];
+    float4 xa[U][MT][2];
+    float4 ga[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * nwaves;
+      if (c < nchunks) {
+        const char* wp = wt + (size_t)c * WBYTES;
+        wraw[u][0] = *reinterpret_cast<const uint4*>(wp);
+        if (WF32) wraw[u][WF32 ? 1 : 0] = *reinterpret_cast<const uint4*>(wp + 1024);
+        const int k0 = c * 32 + q * 8;
+        if (PRO == SMOLTTS_PRO_RMSNORM) {
+          ga[u][0] = *reinterpret_cast<const float4*>(p.gamma + k0);
+          ga[u][1] = *reinterpret_cast<const float4*>(p.gamma + k0 + 4);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          if (xv[mt]) {
+            xa[u][mt][0] = *reinterpret_cast<const float4*>(xrow[mt] + k0);
+            xa[u][mt][1] = *reinterpret_cast<const float4*>(xrow[mt] + k0 + 4);
+          } else {
+            xa[u][mt][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+            xa[u][mt][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+      } else {
+        wraw[u][0] = make_uint4(0, 0, 0, 0);
+        if (WF32) wraw[u][WF32 ? 1 : 0] = make_uint4(0, 0, 0, 0);
+        ga[u][0] = ga[u][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          xa[u][mt][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+          xa[u][mt][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float wv[8];
+      if (WF32) {
+        wv[0] = __uint_as_float(wraw[u][0].x); wv[1] = __uint_as_float(wraw[u][0].y);
+        wv[2] = __uint_as_float(wraw[u][0].z); wv[3] = __uint_as_float(wraw[u][0].w);
+        wv[4] = __uint_as_float(wraw[u][WF32 ? 1 : 0].x); wv[5] = __uint_as_float(wraw[u][WF32 ? 1 : 0].y);
+        wv[6] = __uint_as_float(wraw[u][WF32 ? 1 : 0].z); wv[7] = __uint_as_float(wraw[u][WF32 ? 1 : 0].w);
+      } else {
+        wv[0] = bf16_lo(wraw[u][0].x); wv[1] = bf16_hi(wraw[u][0].x);
+        wv[2] = bf16_lo(wraw[u][0].y); wv[3] = bf16_hi(wraw[u][0].y);
+        wv[4] = bf16_lo(wraw[u][0].z); wv[5] = bf16_hi(wraw[u][0].z);
+        wv[6] = bf16_lo(wraw[u][0].w); wv[7] = bf16_hi(wraw[u][0].w);
+      }
+      float gv[8];
+      if (PRO == SMOLTTS_PRO_RMSNORM) {
+        gv[0] = ga[u][0].x; gv[1] = ga[u][0].y; gv[2] = ga[u][0].z; gv[3] = ga[u][0].w;
+        gv[4] = ga[u][1].x; gv[5] = ga[u][1].y; gv[6] = ga[u][1].z; gv[7] = ga[u][1].w;
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        float xvv[8] = {xa[u][mt][0].x, xa[u][mt][0].y, xa[u][mt][0].z, xa[u][mt][0].w,
+                        xa[u][mt][1].x, xa[u][mt][1].y, xa[u][mt][1].z, xa[u][mt][1].w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float xj = xvv[j];
+          if (PRO == SMOLTTS_PRO_RMSNORM) {
+            ss[mt] = fmaf(xj, xj, ss[mt]);
+            xj *= gv[j];
+          } else if (PRO == SMOLTTS_PRO_ELU) {
+            xj = elu1(xj);
+          }
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], xj, acc[mt], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- cross-wave reduction (fixed order), layout red[wave][mt][reg][lane]
+  float* red = smem;
+  float* ssred = smem + nwaves * MT * 256;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[((wave * MT + mt) * 4 + i) * 64 + lane] = acc[mt][i];
+    if (PRO == SMOLTTS_PRO_RMSNORM) {
+      float s = ss[mt];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (lane < 16) ssred[(wave * MT + mt) * 16 + lane] = s;
+    }
+  }
+  __syncthreads();
+  if (tid >= 64 * MT) return;
+  const int mt = tid >> 6;  // lane, r, q keep their meaning
+  const int m = (mg * MT + mt) * 16 + r;
+  if (m >= p.M) return;
+  float v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float s = 0.f;
+    for (int w = 0; w < nwaves; ++w) s += red[((w * MT + mt) * 4 + i) * 64 + lane];
+    v[i] = s;
+  }
+  if (PRO == SMOLTTS_PRO_RMSNORM) {
+    float tot = 0.f;
+    for (int w = 0; w < nwaves; ++w) tot += ssred[(w * MT + mt) * 16 + r];
+    const float rstd = 1.0f / sqrtf(tot / (float)p.K + p.eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] *= rstd;
+  }
+  const int n0 = nt * 16 + q * 4;
+  if (n0 >= p.N) return;  // N is padded to 16 in the tiles only; N % 4 == 0 is required
+  if (p.bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (n0 + i < p.N) v[i] += p.bias[n0 + i];
+  }
+  const long orow = row_off(m, p.rows_per_batch, p.ldo, p.o_bstride);
+  const long rrow = (EPI == SMOLTTS_EPI_RESID || EPI == SMOLTTS_EPI_SCALE_RESID)
+                        ? row_off(m, p.rows_per_batch, p.ldr, p.r_bstride) : 0;
+
+  if (EPI == SMOLTTS_EPI_STORE) {
+    if (n0 + 4 <= p.N) {
+      *reinterpret_cast<float4*>(p.out + orow + n0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {  // N < 4 (the final 1-channel conv): scalar tail
+      for (int i = 0; i < 4 && n0 + i < p.N; ++i) p.out[orow + n0 + i] = v[i];
+    }
+  } else if (EPI == SMOLTTS_EPI_RESID) {
+    const float4 rr = *reinterpret_cast<const float4*>(p.resid + rrow + n0);
+    *reinterpret_cast<float4*>(p.out + orow + n0) = make_float4(rr.x + v[0], rr.y + v[1], rr.z + v[2], rr.w + v[3]);
+  } else if (EPI == SMOLTTS_EPI_SCALE_RESID) {
+    const float4 rr = *reinterpret_cast<const float4*>(p.resid + rrow + n0);
+    const float4 sc = *reinterpret_cast<const float4*>(p.scale + n0);
+    *reinterpret_cast<float4*>(p.out + orow + n0) =
+        make_float4(rr.x + sc.x * v[0], rr.y + sc.y * v[1], rr.z + sc.z * v[2], rr.w + sc.w * v[3]);
+  } else if (EPI == SMOLTTS_EPI_GELU) {
+    *reinterpret_cast<float4*>(p.out + orow + n0) = make_float4(gelu1(v[0]), gelu1(v[1]), gelu1(v[2]), gelu1(v[3]));
+  } else if (EPI == SMOLTTS_EPI_SWIGLU) {
+    *reinterpret_cast<float2*>(p.out + orow + (n0 >> 1)) = make_float2(silu1(v[0]) * v[1], silu1(v[2]) * v[3]);
+  } else if (EPI == SMOLTTS_EPI_QKV_ROPE) {
+    const int pos = p.row_pos[m], slot = p.row_slot[m];
+    const int qd = p.n_q_heads * 64, kd = p.n_kv_heads * 64;
+    if (n0 < qd + kd) {
+      const float4 cs = *reinterpret_cast<const float4*>(p.rope + ((long)pos * 32 + ((n0 & 63) >> 1)) * 2);
+      const float o0 = v[0] * cs.x - v[1] * cs.y, o1 = v[1] * cs.x + v[0] * cs.y;
+      const float o2 = v[2] * cs.z - v[3] * cs.w, o3 = v[3] * cs.z + v[2] * cs.w;
+      v[0] = o0; v[1] = o1; v[2] = o2; v[3] = o3;
+    }
+    const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+    if (n0 < qd) {
+      *reinterpret_cast<float4*>(p.out + orow + n0) = o;
+    } else if (pos >= 0 && pos < p.cache_len) {
+      const int nn = n0 - qd;
+      float* base = nn < kd ? p.kc : p.vc;
+      const int h = (nn < kd ? nn : nn - kd) >> 6, d = nn & 63;
+      *reinterpret_cast<float4*>(base + (((long)slot * p.n_kv_heads + h) * p.cache_len + pos) * 64 + d) = o;
+    }
+  }
+}
+
+template <bool WF32, int MT, int U, int PRO, int EPI>
+static int launch_one(const GemmDev& d, int nwaves, hipStream_t stream) {
+  const dim3 grid((d.N + 15) / 16, (d.M + 16 * MT - 1) / (16 * MT));
+  const size_t lds = (size_t)nwaves * MT * (256 + 16) * sizeof(float);
+  hipLaunchKernelGGL((gemm_kernel<WF32, MT, U, PRO, EPI>), grid, dim3(nwaves * 64), lds, stream, d);
+  ST_CHECK_HIP(hipGetLastError());
+  return SMOLTTS_OK;
+}
+
+template <bool WF32, int PRO, int EPI>
+static int launch_mt(const GemmDev& d, int nwaves, hipStream_t stream) {
+  if (d.M <= 16) return launch_one<WF32, 1, 3, PRO, EPI>(d, nwaves, stream);
+  if (d.M <= 32) return launch_one<WF32, 2, 3, PRO, EPI>(d, nwaves, stream);
+  return launch_one<WF32, 4, 2, PRO, EPI>(d, nwaves, stream);
+}
+
+int launch_gemm(const SmolttsGemmArgs& a, hipStream_t stream) {
+  ST_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, SMOLTTS_E_INVALID, "gemm: empty shape M=%d N=%d K=%d", a.M, a.N, a.K);
+  ST_REQUIRE(a.K % 32 == 0, SMOLTTS_E_INVALID, "gemm: K=%d must be a multiple of 32", a.K);
+  ST_REQUIRE(a.N % 4 == 0 || a.N < 4, SMOLTTS_E_INVALID, "gemm: N=%d must be a multiple of 4", a.N);
+  ST_REQUIRE(a.w_dev && a.x_dev, SMOLTTS_E_INVALID, "gemm: null operand");
+  ST_REQUIRE(a.ldx % 4 == 0 && a.x_bstride % 4 == 0, SMOLTTS_E_INVALID,
+             "gemm: x strides must keep 16-byte alignment (ldx=%ld)", (long)a.ldx);
+  ST_REQUIRE(a.N < 4 || (a.ldo % 4 == 0 && a.o_bstride % 4 == 0) ||
+                 (a.epilogue == SMOLTTS_EPI_SWIGLU && a.ldo % 2 == 0 && a.o_bstride % 2 == 0),
+             SMOLTTS_E_INVALID, "gemm: out strides must keep 16-byte alignment (ldo=%ld)", (long)a.ldo);
+  ST_REQUIRE(a.ldr % 4 == 0 && a.r_bstride % 4 == 0, SMOLTTS_E_INVALID, "gemm: resid strides must keep 16-byte alignment");
+  ST_REQUIRE(a.N >= 4 || a.epilogue == SMOLTTS_EPI_STORE, SMOLTTS_E_INVALID, "gemm: N < 4 only with EPI_STORE");
+  ST_REQUIRE((long)((a.M + 63) / 64) <= 65535, SMOLTTS_E_INVALID, "gemm: M=%d too large for one launch", a.M);
+  GemmDev d;
+  d.w = (const char*)a.w_dev; d.x = a.x_dev; d.ldx = a.ldx; d.x_bstride = a.x_bstride;
+  d.rows_per_batch = a.rows_per_batch; d.M = a.M; d.N = a.N; d.K = a.K; d.gamma = a.gamma_dev; d.eps = a.eps;
+  d.bias = a.bias_dev; d.scale = a.scale_dev; d.resid = a.resid_dev; d.out = a.out_dev; d.ldo = a.ldo;
+  d.o_bstride = a.o_bstride; d.ldr = a.ldr ? a.ldr : a.ldo; d.r_bstride = a.ldr ? a.r_bstride : a.o_bstride;
+  d.rope = a.rope_dev; d.row_pos = a.row_pos_dev; d.row_slot = a.row_slot_dev;
+  d.kc = a.k_cache_dev; d.vc = a.v_cache_dev; d.n_q_heads = a.n_q_heads; d.n_kv_heads = a.n_kv_heads;
+  d.cache_len = a.cache_len;
+  const int nchunks = a.K / 32;
+  // waves split K: keep ~3 chunks per wave, at most 16 waves
+  int nwaves = (nchunks + 2) / 3;
+  nwaves = nwaves < 1 ? 1 : (nwaves > 16 ? 16 : nwaves);
+  if (a.M > 32 && nwaves > 8) nwaves = 8;  // MT=4 instantiation: stay inside the register budget
+  const int mt_used = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
+  if (nwaves < mt_used) nwaves = mt_used;  // the epilogue needs one wave per 16-row tile
+  const int P = a.prologue, E = a.epilogue;
+  if (P == SMOLTTS_PRO_RMSNORM) ST_REQUIRE(a.gamma_dev, SMOLTTS_E_INVALID, "gemm: RMSNorm prologue needs gamma");
+  if (E == SMOLTTS_EPI_RESID || E == SMOLTTS_EPI_SCALE_RESID)
+    ST_REQUIRE(a.resid_dev && a.out_dev, SMOLTTS_E_INVALID, "gemm: residual epilogue needs resid/out");
+  if (E == SMOLTTS_EPI_SCALE_RESID) ST_REQUIRE(a.scale_dev, SMOLTTS_E_INVALID, "gemm: scale missing");
+  if (E == SMOLTTS_EPI_QKV_ROPE)
+    ST_REQUIRE(a.rope_dev && a.row_pos_dev && a.row_slot_dev && a.k_cache_dev && a.v_cache_dev && a.out_dev &&
+                   a.N == (a.n_q_heads + 2 * a.n_kv_heads) * 64 && a.cache_len > 0,
+               SMOLTTS_E_INVALID, "gemm: QKV_ROPE epilogue arguments inconsistent");
+  else
+    ST_REQUIRE(a.out_dev, SMOLTTS_E_INVALID, "gemm: null output");
+
+#define ST_CASE(WF, PP, EE)                                                       \
+  if ((a.w_is_fp32 != 0) == WF && P == PP && E == EE) return launch_mt<WF, PP, EE>(d, nwaves, stream);
+  // bf16 weights: the DualAR transformer
+  ST_CASE(false, SMOLTTS_PRO_RMSNORM, SMOLTTS_EPI_QKV_ROPE)
+  ST_CASE(false, SMOLTTS_PRO_NONE, SMOLTTS_EPI_RESID)
+  ST_CASE(false, SMOLTTS_PRO_RMSNORM, SMOLTTS_EPI_SWIGLU)
+  ST_CASE(false, SMOLTTS_PRO_RMSNORM, SMOLTTS_EPI_STORE)
+  ST_CASE(false, SMOLTTS_PRO_NONE, SMOLTTS_EPI_STORE)
+  // fp32 weights: the Mimi decoder
+  ST_CASE(true, SMOLTTS_PRO_NONE, SMOLTTS_EPI_QKV_ROPE)
+  ST_CASE(true, SMOLTTS_PRO_NONE, SMOLTTS_EPI_SCALE_RESID)
+  ST_CASE(true, SMOLTTS_PRO_NONE, SMOLTTS_EPI_GELU)
+  ST_CASE(true, SMOLTTS_PRO_NONE, SMOLTTS_EPI_STORE)
+  ST_CASE(true, SMOLTTS_PRO_ELU, SMOLTTS_EPI_STORE)
+  ST_CASE(true, SMOLTTS_PRO_ELU, SMOLTTS_EPI_RESID)
+#undef ST_CASE
+  set_error("gemm: unsupported combination w_is_fp32=%d prologue=%d epilogue=%d", a.w_is_fp32, P, E);
+  return SMOLTTS_E_INVALID;
+}
+
+}  // namespace smoltts

@@ -1,0 +1,473 @@
+// DualAR engine: orchestrates the kernels into prefill / frame-decode launch sequences.
+//
+// One frame == one SingleBatchGenerator.__next__ of the reference (lm/generate.py:59-171) for every
+// slot of the session at once:  slow transformer step (forward_generate, lm/rq_transformer.py:173-192)
+// -> argmax -> n_fast depth-transformer steps with a per-frame KV cache (forward_generate_fast :194-220,
+// generate.py:110-141) -> commit of the (1 + n_fast)-high column.  Sampling, the column feedback, the
+// stop rule and the position counters all live on the device, so a frame is a fixed launch sequence that
+// is captured once into a hipGraph and replayed (the reference synchronises with the host 9x per frame).
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+using namespace smoltts;
+
+struct SmolttsEngine {
+  SmolttsLMConfig cfg;
+  SmolttsLMWeights w;
+  const char* arena;
+  size_t arena_bytes;
+};
+
+struct SmolttsSession {
+  SmolttsEngine* e;
+  int B, max_seq, max_rows, max_frames;
+  int stop_on_eos;
+  // activations
+  float *xr, *qr, *ar, *hr;  // prefill rows: [max_rows][dim | Hq*64 | dim | inter]
+  float *xt, *xf;            // [B][dim], [B][fast_dim]
+  float *qt, *at, *ht;       // decode/tail rows [B][...] sized for max(slow, fast)
+  float* logits;             // [B][max(vocab, codebook)]
+  // caches
+  float *kc, *vc;            // [n_layer][B][KV][max_seq][64]
+  float *fkc, *fvc;          // [n_fast_layer][B][FKV][n_fast][64]
+  // integer state
+  int *cur_col, *new_col;    // [B][1+n_fast]
+  int *pos, *frames, *done, *mask, *iota, *fastpos;  // [B] each; fastpos [n_fast][B]
+  int *stage_slots, *stage_last;                     // [B]
+  float* margin;             // [B]
+  int* codes;                // [B][max_frames][1+n_fast]
+  // host staging (pinned)
+  int* h_stage;
+  hipGraphExec_t graph_exec;
+  bool graph_ready;
+  bool prefilled;
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct Carver {
+  char* base;
+  size_t off;
+  template <typename T>
+  T* take(size_t n) {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off = align_up(off + n * sizeof(T));
+    return p;
+  }
+};
+
+int imax(int a, int b) { return a > b ? a : b; }
+
+void carve(SmolttsSession* s, char* base, size_t* total) {
+  const SmolttsLMConfig& c = s->e->cfg;
+  Carver cv{base, 0};
+  const size_t B = s->B, R = s->max_rows, H = 1 + c.n_fast;
+  const size_t dq = (size_t)imax(c.n_head, c.fast_n_head) * 64;
+  const size_t dmax = imax(c.dim, c.fast_dim), imx = imax(c.inter, c.fast_inter);
+  s->xr = cv.take<float>(R * c.dim);
+  s->qr = cv.take<float>(R * c.n_head * 64);
+  s->ar = cv.take<float>(R * c.dim);
+  s->hr = cv.take<float>(R * c.inter);
+  s->xt = cv.take<float>(B * c.dim);
+  s->xf = cv.take<float>(B * c.fast_dim);
+  s->qt = cv.take<float>(B * dq);
+  s->at = cv.take<float>(B * dmax);
+  s->ht = cv.take<float>(B * imx);
+  s->logits = cv.take<float>(B * (size_t)imax(c.vocab_size, c.codebook_size));
+  const size_t kv = (size_t)c.n_layer * B * c.n_kv_head * s->max_seq * 64;
+  s->kc = cv.take<float>(kv);
+  s->vc = cv.take<float>(kv);
+  const size_t fkv = (size_t)c.n_fast_layer * B * c.fast_n_kv_head * c.n_fast * 64;
+  s->fkc = cv.take<float>(fkv);
+  s->fvc = cv.take<float>(fkv);
+  s->cur_col = cv.take<int>(B * H);
+  s->new_col = cv.take<int>(B * H);
+  s->pos = cv.take<int>(B);
+  s->frames = cv.take<int>(B);
+  s->done = cv.take<int>(B);
+  s->mask = cv.take<int>(B);
+  s->iota = cv.take<int>(B);
+  s->fastpos = cv.take<int>((size_t)c.n_fast * B);
+  s->stage_slots = cv.take<int>(B);
+  s->stage_last = cv.take<int>(B);
+  s->margin = cv.take<float>(B);
+  s->codes = cv.take<int>(B * (size_t)s->max_frames * H);
+  *total = cv.off;
+}
+
+__global__ void init_state_kernel(int B, int n_fast, int* iota, int* fastpos, int* pos, int* frames, int* done, int* mask,
+                                  float* margin, int* cur_col, int* new_col) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  iota[b] = b;
+  for (int i = 0; i < n_fast; ++i) fastpos[i * B + b] = i;
+  pos[b] = 0; frames[b] = 0; done[b] = 1; mask[b] = 0;
+  margin[b] = INFINITY;
+  for (int i = 0; i <= n_fast; ++i) { cur_col[b * (1 + n_fast) + i] = 0; new_col[b * (1 + n_fast) + i] = 0; }
+}
+
+// Restart the listed slots: position = prompt length, counters cleared; only they commit this frame.
+__global__ void slot_reset_kernel(int B, int n_slots, const int* slots, const int* last_row, const int* row_pos, int* pos,
+                                  int* frames, int* done, int* mask, float* margin) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int hit = -1;
+  for (int i = 0; i < n_slots; ++i)
+    if (slots[i] == b) hit = i;
+  mask[b] = hit >= 0;
+  if (hit >= 0) {
+    pos[b] = row_pos[last_row[hit]] + 1;
+    frames[b] = 0; done[b] = 0; margin[b] = INFINITY;
+  }
+}
+
+// xt[slots[i]] = xr[last_row[i]]
+__global__ __launch_bounds__(256) void scatter_last_kernel(const float* xr, const int* slots, const int* last_row, int dim,
+                                                           float* xt) {
+  const int i = blockIdx.x;
+  const long s = last_row[i], d0 = slots[i];
+  for (int d = threadIdx.x * 4; d < dim; d += 256 * 4)
+    *reinterpret_cast<float4*>(xt + d0 * dim + d) = *reinterpret_cast<const float4*>(xr + s * dim + d);
+}
+
+__global__ void decode_mask_kernel(int B, const int* done, int* mask) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) mask[b] = !done[b];
+}
+
+// End of frame (lm/generate.py:143-171): publish the column, advance counters, apply the stop rule.
+// `advance_pos`: the slow step of this frame consumed one new token (decode) vs. the prompt (prefill).
+__global__ void commit_kernel(int B, int H, int max_frames, int im_end, int stop_on_eos, int advance_pos, const int* mask,
+                              const int* new_col, int* cur_col, int* codes, int* pos, int* frames, int* done) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B || !mask[b]) return;
+  const int f = frames[b];
+  if (advance_pos) pos[b] += 1;
+  if (f < max_frames) {
+    for (int i = 0; i < H; ++i) {
+      const int v = new_col[b * H + i];
+      cur_col[b * H + i] = v;
+      codes[((long)b * max_frames + f) * H + i] = v;
+    }
+    frames[b] = f + 1;
+  }
+  if ((stop_on_eos && new_col[b * H] == im_end) || f + 1 >= max_frames) done[b] = 1;
+}
+
+SmolttsGemmArgs base_gemm(const void* w, const float* x, long ldx, int M, int N, int K) {
+  SmolttsGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.w_dev = w; a.w_is_fp32 = 0; a.x_dev = x; a.ldx = ldx; a.M = M; a.N = N; a.K = K;
+  return a;
+}
+
+// One pre-norm block (modeling/model/rq_transformer.py:492-501) over `M` rows held in x (in place).
+int run_block(const SmolttsEngine* e, const SmolttsBlockWeights& bw, int dim, int n_head, int n_kv, int inter, float* x,
+              float* q, float* attn, float* h, int M, const int* row_pos, const int* row_slot, const float* rope, float* kc,
+              float* vc, int cache_len, hipStream_t st) {
+  const char* A = e->arena;
+  const float eps = e->cfg.norm_eps;
+  {  // RMSNorm + QKV + RoPE + cache write
+    SmolttsGemmArgs a = base_gemm(A + bw.wqkv, x, dim, M, (n_head + 2 * n_kv) * 64, dim);
+    a.prologue = SMOLTTS_PRO_RMSNORM; a.epilogue = SMOLTTS_EPI_QKV_ROPE;
+    a.gamma_dev = (const float*)(A + bw.attn_norm); a.eps = eps;
+    a.out_dev = q; a.ldo = n_head * 64;
+    a.rope_dev = rope; a.row_pos_dev = row_pos; a.row_slot_dev = row_slot;
+    a.k_cache_dev = kc; a.v_cache_dev = vc; a.n_q_heads = n_head; a.n_kv_heads = n_kv; a.cache_len = cache_len;
+    ST_TRY(launch_gemm(a, st));
+  }
+  ST_TRY(launch_attention(q, kc, vc, row_pos, row_slot, M, n_head, n_kv, cache_len, 0, attn, st));
+  {  // x += attn . Wo^T
+    SmolttsGemmArgs a = base_gemm(A + bw.wo, attn, dim, M, dim, dim);
+    a.epilogue = SMOLTTS_EPI_RESID; a.resid_dev = x; a.out_dev = x; a.ldo = dim;
+    ST_TRY(launch_gemm(a, st));
+  }
+  {  // h = silu(w1 n) * (w3 n), n = RMSNorm(x)
+    SmolttsGemmArgs a = base_gemm(A + bw.w13, x, dim, M, 2 * inter, dim);
+    a.prologue = SMOLTTS_PRO_RMSNORM; a.epilogue = SMOLTTS_EPI_SWIGLU;
+    a.gamma_dev = (const float*)(A + bw.ffn_norm); a.eps = eps;
+    a.out_dev = h; a.ldo = inter;
+    ST_TRY(launch_gemm(a, st));
+  }
+  {  // x += h . W2^T
+    SmolttsGemmArgs a = base_gemm(A + bw.w2, h, inter, M, dim, inter);
+    a.epilogue = SMOLTTS_EPI_RESID; a.resid_dev = x; a.out_dev = x; a.ldo = dim;
+    ST_TRY(launch_gemm(a, st));
+  }
+  return SMOLTTS_OK;
+}
+
+// Slow head + the depth transformer for all B slots; columns land in new_col, commit applies `mask`.
+int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
+  const SmolttsEngine* e = s->e;
+  const SmolttsLMConfig& c = e->cfg;
+  const char* A = e->arena;
+  const int B = s->B, H = 1 + c.n_fast;
+  {  // logits = RMSNorm(x) . E^T   (lm/rq_transformer.py:184-189)
+    SmolttsGemmArgs a = base_gemm(A + e->w.head, s->xt, c.dim, B, c.vocab_size, c.dim);
+    a.prologue = SMOLTTS_PRO_RMSNORM; a.epilogue = SMOLTTS_EPI_STORE;
+    a.gamma_dev = (const float*)(A + e->w.norm); a.eps = c.norm_eps;
+    a.out_dev = s->logits; a.ldo = c.vocab_size;
+    ST_TRY(launch_gemm(a, st));
+  }
+  ST_TRY(launch_argmax(s->logits, B, c.vocab_size, c.vocab_size, s->new_col, H, s->margin, s->mask, nullptr, 0, 0, nullptr, st));
+  float* xf = s->xt;  // fast input = pre-norm slow hidden (lm/rq_transformer.py:191)
+  if (c.has_fast_project_in) {
+    SmolttsGemmArgs a = base_gemm(A + e->w.fast_proj_w, s->xt, c.dim, B, c.fast_dim, c.dim);
+    a.epilogue = SMOLTTS_EPI_STORE; a.bias_dev = (const float*)(A + e->w.fast_proj_b);
+    a.out_dev = s->xf; a.ldo = c.fast_dim;
+    ST_TRY(launch_gemm(a, st));
+    xf = s->xf;
+  }
+  const size_t fl_stride = (size_t)B * c.fast_n_kv_head * c.n_fast * 64;
+  for (int i = 0; i < c.n_fast; ++i) {
+    for (int l = 0; l < c.n_fast_layer; ++l)
+      ST_TRY(run_block(e, e->w.fast_layers[l], c.fast_dim, c.fast_n_head, c.fast_n_kv_head, c.fast_inter, xf, s->qt, s->at,
+                       s->ht, B, s->fastpos + (size_t)i * B, s->iota, (const float*)(A + e->w.fast_rope),
+                       s->fkc + l * fl_stride, s->fvc + l * fl_stride, c.n_fast, st));
+    {  // fast_norm + depthwise head slice i  (lm/rq_transformer.py:209-217)
+      const size_t wrow = (size_t)i * e->w.fast_head_step_stride;  // rows; a row tile is 16 rows
+      SmolttsGemmArgs a = base_gemm(A + e->w.fast_head + wrow * c.fast_dim * 2, xf, c.fast_dim, B, c.codebook_size, c.fast_dim);
+      a.prologue = SMOLTTS_PRO_RMSNORM; a.epilogue = SMOLTTS_EPI_STORE;
+      a.gamma_dev = (const float*)(A + e->w.fast_norm); a.eps = c.norm_eps;
+      a.out_dev = s->logits; a.ldo = c.codebook_size;
+      ST_TRY(launch_gemm(a, st));
+    }
+    const bool more = i + 1 < c.n_fast;
+    const int off = c.depthwise_wte ? (c.duplicate_code_0 ? i : i + 1) * c.codebook_size : 0;  // generate.py:136-140
+    // from step 1 on the fast input lives in xf's own buffer (never clobber the slow hidden twice)
+    float* xnext = c.has_fast_project_in ? s->xf : s->xt;
+    ST_TRY(launch_argmax(s->logits, B, c.codebook_size, c.codebook_size, s->new_col + 1 + i, H, s->margin, s->mask,
+                         more ? (const void*)(A + e->w.fast_emb) : nullptr, off, c.fast_dim, more ? xnext : nullptr, st));
+    xf = xnext;
+  }
+  hipLaunchKernelGGL(commit_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, H, s->max_frames, c.im_end_id, s->stop_on_eos,
+                     advance_pos, s->mask, s->new_col, s->cur_col, s->codes, s->pos, s->frames, s->done);
+  ST_CHECK_HIP(hipGetLastError());
+  return SMOLTTS_OK;
+}
+
+int run_decode_frame(SmolttsSession* s, hipStream_t st) {
+  const SmolttsEngine* e = s->e;
+  const SmolttsLMConfig& c = e->cfg;
+  const char* A = e->arena;
+  const int B = s->B;
+  hipLaunchKernelGGL(decode_mask_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, s->done, s->mask);
+  ST_CHECK_HIP(hipGetLastError());
+  const int cb_first = c.duplicate_code_0 ? 0 : c.codebook_size;
+  ST_TRY(launch_embed(s->cur_col, B, c.n_fast, A + e->w.text_emb, A + e->w.codebook_emb, c.dim, c.codebook_size, cb_first,
+                      c.embed_mask_mode, c.semantic_start_id, c.semantic_end_id, c.vocab_size,
+                      c.codebook_size * c.num_codebooks, s->xt, st));
+  const size_t l_stride = (size_t)B * c.n_kv_head * s->max_seq * 64;
+  for (int l = 0; l < c.n_layer; ++l)
+    ST_TRY(run_block(e, e->w.layers[l], c.dim, c.n_head, c.n_kv_head, c.inter, s->xt, s->qt, s->at, s->ht, B, s->pos, s->iota,
+                     (const float*)(A + e->w.rope), s->kc + l * l_stride, s->vc + l * l_stride, s->max_seq, st));
+  return run_tail(s, /*advance_pos=*/1, st);
+}
+
+int check_offsets(const SmolttsLMConfig& c, const SmolttsLMWeights& w, size_t bytes) {
+  auto ok = [&](uint64_t off, size_t need) { return off % 16 == 0 && off + need <= bytes; };
+  const size_t d = c.dim, fd = c.fast_dim;
+  ST_REQUIRE(ok(w.text_emb, (size_t)c.vocab_size * d * 2) && ok(w.head, (size_t)c.vocab_size * d * 2) &&
+                 ok(w.codebook_emb, (size_t)c.codebook_size * c.num_codebooks * d * 2) && ok(w.norm, d * 4) &&
+                 ok(w.fast_norm, fd * 4) && ok(w.rope, (size_t)c.max_seq_len * 64 * 4) && ok(w.fast_rope, (size_t)c.n_fast * 64 * 4),
+             SMOLTTS_E_INVALID, "engine: weight offsets outside the arena or misaligned");
+  const size_t head_rows = (size_t)(c.n_fast - 1) * w.fast_head_step_stride + c.codebook_size;
+  ST_REQUIRE(ok(w.fast_head, head_rows * fd * 2), SMOLTTS_E_INVALID, "engine: fast_head outside the arena");
+  ST_REQUIRE(w.fast_head_step_stride % 16 == 0, SMOLTTS_E_INVALID, "engine: fast_head_step_stride must be a multiple of 16");
+  for (int l = 0; l < c.n_layer + c.n_fast_layer; ++l) {
+    const bool fast = l >= c.n_layer;
+    const SmolttsBlockWeights& b = fast ? w.fast_layers[l - c.n_layer] : w.layers[l];
+    const size_t dd = fast ? fd : d, hh = fast ? c.fast_n_head : c.n_head, kk = fast ? c.fast_n_kv_head : c.n_kv_head;
+    const size_t ii = fast ? c.fast_inter : c.inter;
+    ST_REQUIRE(ok(b.attn_norm, dd * 4) && ok(b.ffn_norm, dd * 4) && ok(b.wqkv, (hh + 2 * kk) * 64 * dd * 2) &&
+                   ok(b.wo, dd * dd * 2) && ok(b.w13, 2 * ii * dd * 2) && ok(b.w2, dd * ii * 2),
+               SMOLTTS_E_INVALID, "engine: layer %d weight offsets outside the arena or misaligned", l);
+  }
+  return SMOLTTS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smoltts_engine_create(const SmolttsLMConfig* cfg, const SmolttsLMWeights* offsets, const void* arena_dev,
+                          size_t arena_bytes, SmolttsEngine** out) {
+  ST_REQUIRE(cfg && offsets && arena_dev && out, SMOLTTS_E_INVALID, "engine_create: null argument");
+  const SmolttsLMConfig& c = *cfg;
+  ST_REQUIRE(c.n_layer > 0 && c.n_layer <= SMOLTTS_MAX_LAYERS && c.n_fast_layer > 0 && c.n_fast_layer <= SMOLTTS_MAX_FAST_LAYERS,
+             SMOLTTS_E_INVALID, "engine_create: layer counts out of range");
+  ST_REQUIRE(c.dim == c.n_head * 64 && c.fast_dim == c.fast_n_head * 64, SMOLTTS_E_INVALID,
+             "engine_create: dim must equal n_head * 64 (head_dim 64 only)");
+  ST_REQUIRE(c.dim % 32 == 0 && c.fast_dim % 32 == 0 && c.inter % 32 == 0 && c.fast_inter % 32 == 0, SMOLTTS_E_INVALID,
+             "engine_create: dims must be multiples of 32");
+  ST_REQUIRE(c.n_head % c.n_kv_head == 0 && c.fast_n_head % c.fast_n_kv_head == 0 && c.n_head / c.n_kv_head <= 4 &&
+                 c.fast_n_head / c.fast_n_kv_head <= 4,
+             SMOLTTS_E_INVALID, "engine_create: unsupported GQA grouping");
+  ST_REQUIRE(c.vocab_size % 16 == 0 && c.codebook_size % 16 == 0, SMOLTTS_E_INVALID,
+             "engine_create: vocab_size and codebook_size must be multiples of 16");
+  ST_REQUIRE(c.n_fast == c.num_codebooks - (c.duplicate_code_0 ? 0 : 1) && c.n_fast >= 1 && c.n_fast <= 32, SMOLTTS_E_INVALID,
+             "engine_create: n_fast inconsistent with num_codebooks/duplicate_code_0");
+  ST_REQUIRE(c.has_fast_project_in == (c.fast_dim != c.dim), SMOLTTS_E_INVALID,
+             "engine_create: has_fast_project_in must be set exactly when fast_dim != dim");
+  ST_REQUIRE(c.max_seq_len > 0, SMOLTTS_E_INVALID, "engine_create: max_seq_len");
+  ST_TRY(check_offsets(c, *offsets, arena_bytes));
+  SmolttsEngine* e = new (std::nothrow) SmolttsEngine;
+  ST_REQUIRE(e, SMOLTTS_E_INVALID, "engine_create: out of host memory");
+  e->cfg = c; e->w = *offsets; e->arena = (const char*)arena_dev; e->arena_bytes = arena_bytes;
+  *out = e;
+  return SMOLTTS_OK;
+}
+
+void smoltts_engine_destroy(SmolttsEngine* e) { delete e; }
+
+size_t smoltts_session_slab_bytes(const SmolttsEngine* e, int32_t max_batch, int32_t max_seq, int32_t max_rows,
+                                  int32_t max_frames) {
+  if (!e || max_batch <= 0 || max_seq <= 0 || max_rows <= 0 || max_frames <= 0) return 0;
+  SmolttsSession tmp;
+  memset(&tmp, 0, sizeof(tmp));
+  tmp.e = const_cast<SmolttsEngine*>(e);
+  tmp.B = max_batch; tmp.max_seq = max_seq; tmp.max_rows = max_rows; tmp.max_frames = max_frames;
+  size_t total = 0;
+  carve(&tmp, nullptr, &total);
+  return total;
+}
+
+int smoltts_session_create(SmolttsEngine* e, void* slab_dev, size_t slab_bytes, int32_t max_batch, int32_t max_seq,
+                           int32_t max_rows, int32_t max_frames, SmolttsSession** out) {
+  ST_REQUIRE(e && slab_dev && out, SMOLTTS_E_INVALID, "session_create: null argument");
+  ST_REQUIRE(max_batch > 0 && max_batch <= 4096 && max_rows > 0 && max_frames > 0, SMOLTTS_E_INVALID, "session_create: bad sizes");
+  ST_REQUIRE(max_seq > 0 && max_seq <= e->cfg.max_seq_len, SMOLTTS_E_CAPACITY,
+             "session_create: max_seq %d exceeds the RoPE table (%d)", max_seq, e->cfg.max_seq_len);
+  ST_REQUIRE(((uintptr_t)slab_dev & 255) == 0, SMOLTTS_E_INVALID, "session_create: slab must be 256-byte aligned");
+  const size_t need = smoltts_session_slab_bytes(e, max_batch, max_seq, max_rows, max_frames);
+  ST_REQUIRE(slab_bytes >= need, SMOLTTS_E_CAPACITY, "session_create: slab has %zu bytes, %zu needed", slab_bytes, need);
+  SmolttsSession* s = new (std::nothrow) SmolttsSession;
+  ST_REQUIRE(s, SMOLTTS_E_INVALID, "session_create: out of host memory");
+  memset(s, 0, sizeof(*s));
+  s->e = e; s->B = max_batch; s->max_seq = max_seq; s->max_rows = max_rows; s->max_frames = max_frames;
+  size_t total = 0;
+  carve(s, (char*)slab_dev, &total);
+  if (hipHostMalloc((void**)&s->h_stage, sizeof(int) * 2 * max_batch, hipHostMallocDefault) != hipSuccess) {
+    delete s;
+    set_error("session_create: hipHostMalloc failed");
+    return SMOLTTS_E_HIP;
+  }
+  hipLaunchKernelGGL(init_state_kernel, dim3((max_batch + 63) / 64), dim3(64), 0, 0, max_batch, e->cfg.n_fast, s->iota,
+                     s->fastpos, s->pos, s->frames, s->done, s->mask, s->margin, s->cur_col, s->new_col);
+  hipError_t err = hipGetLastError();
+  if (err == hipSuccess) err = hipStreamSynchronize(0);
+  if (err != hipSuccess) {
+    (void)hipHostFree(s->h_stage);
+    delete s;
+    set_error("session_create: init kernel failed: %s", hipGetErrorString(err));
+    return SMOLTTS_E_HIP;
+  }
+  *out = s;
+  return SMOLTTS_OK;
+}
+
+void smoltts_session_destroy(SmolttsSession* s) {
+  if (!s) return;
+  if (s->graph_ready) (void)hipGraphExecDestroy(s->graph_exec);
+  if (s->h_stage) (void)hipHostFree(s->h_stage);
+  delete s;
+}
+
+int smoltts_lm_prefill(SmolttsSession* s, const int32_t* grid_dev, const int32_t* row_slot_dev, const int32_t* row_pos_dev,
+                       int32_t n_rows, const int32_t* slots_host, const int32_t* last_row_host, int32_t n_slots,
+                       int32_t stop_on_eos, void* stream) {
+  ST_REQUIRE(s && grid_dev && row_slot_dev && row_pos_dev && slots_host && last_row_host, SMOLTTS_E_INVALID,
+             "lm_prefill: null argument");
+  ST_REQUIRE(n_rows > 0 && n_rows <= s->max_rows, SMOLTTS_E_CAPACITY, "lm_prefill: %d rows, session holds %d", n_rows, s->max_rows);
+  ST_REQUIRE(n_slots > 0 && n_slots <= s->B, SMOLTTS_E_CAPACITY, "lm_prefill: %d slots, session holds %d", n_slots, s->B);
+  for (int i = 0; i < n_slots; ++i) {
+    ST_REQUIRE(slots_host[i] >= 0 && slots_host[i] < s->B, SMOLTTS_E_INVALID, "lm_prefill: slot %d out of range", slots_host[i]);
+    ST_REQUIRE(last_row_host[i] >= 0 && last_row_host[i] < n_rows, SMOLTTS_E_INVALID, "lm_prefill: last_row %d out of range", last_row_host[i]);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const SmolttsEngine* e = s->e;
+  const SmolttsLMConfig& c = e->cfg;
+  const char* A = e->arena;
+  if (s->stop_on_eos != stop_on_eos && s->graph_ready) {  // the flag is baked into the captured commit node
+    (void)hipGraphExecDestroy(s->graph_exec);
+    s->graph_ready = false;
+  }
+  s->stop_on_eos = stop_on_eos;
+  // the staging buffer may still be read by an earlier async copy on this stream
+  ST_CHECK_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < n_slots; ++i) { s->h_stage[i] = slots_host[i]; s->h_stage[s->B + i] = last_row_host[i]; }
+  ST_CHECK_HIP(hipMemcpyAsync(s->stage_slots, s->h_stage, sizeof(int) * n_slots, hipMemcpyHostToDevice, st));
+  ST_CHECK_HIP(hipMemcpyAsync(s->stage_last, s->h_stage + s->B, sizeof(int) * n_slots, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(slot_reset_kernel, dim3((s->B + 63) / 64), dim3(64), 0, st, s->B, n_slots, s->stage_slots, s->stage_last,
+                     row_pos_dev, s->pos, s->frames, s->done, s->mask, s->margin);
+  ST_CHECK_HIP(hipGetLastError());
+  const int cb_first = c.duplicate_code_0 ? 0 : c.codebook_size;
+  ST_TRY(launch_embed(grid_dev, n_rows, c.n_fast, A + e->w.text_emb, A + e->w.codebook_emb, c.dim, c.codebook_size, cb_first,
+                      c.embed_mask_mode, c.semantic_start_id, c.semantic_end_id, c.vocab_size,
+                      c.codebook_size * c.num_codebooks, s->xr, st));
+  const size_t l_stride = (size_t)s->B * c.n_kv_head * s->max_seq * 64;
+  for (int l = 0; l < c.n_layer; ++l)
+    ST_TRY(run_block(e, e->w.layers[l], c.dim, c.n_head, c.n_kv_head, c.inter, s->xr, s->qr, s->ar, s->hr, n_rows, row_pos_dev,
+                     row_slot_dev, (const float*)(A + e->w.rope), s->kc + l * l_stride, s->vc + l * l_stride, s->max_seq, st));
+  hipLaunchKernelGGL(scatter_last_kernel, dim3(n_slots), dim3(256), 0, st, s->xr, s->stage_slots, s->stage_last, c.dim, s->xt);
+  ST_CHECK_HIP(hipGetLastError());
+  ST_TRY(run_tail(s, /*advance_pos=*/0, st));
+  s->prefilled = true;
+  return SMOLTTS_OK;
+}
+
+int smoltts_lm_decode(SmolttsSession* s, int32_t n_frames, void* stream) {
+  ST_REQUIRE(s, SMOLTTS_E_INVALID, "lm_decode: null session");
+  ST_REQUIRE(s->prefilled, SMOLTTS_E_STATE, "lm_decode: call smoltts_lm_prefill first");
+  ST_REQUIRE(n_frames >= 0, SMOLTTS_E_INVALID, "lm_decode: n_frames < 0");
+  hipStream_t st = (hipStream_t)stream;
+  const char* no_graph = getenv("SMOLTTS_NO_GRAPH");
+  if (no_graph && no_graph[0] == '1') {
+    for (int f = 0; f < n_frames; ++f) ST_TRY(run_decode_frame(s, st));
+    return SMOLTTS_OK;
+  }
+  if (!s->graph_ready) {
+    hipStream_t cap = st;
+    bool own = false;
+    if (cap == nullptr) {  // the legacy default stream cannot be captured
+      ST_CHECK_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+      own = true;
+    }
+    ST_CHECK_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+    const int rc = run_decode_frame(s, cap);
+    hipGraph_t graph = nullptr;
+    const hipError_t ee = hipStreamEndCapture(cap, &graph);
+    if (own) (void)hipStreamDestroy(cap);
+    if (rc != SMOLTTS_OK) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return rc;
+    }
+    ST_CHECK_HIP(ee);
+    const hipError_t ei = hipGraphInstantiate(&s->graph_exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    ST_CHECK_HIP(ei);
+    s->graph_ready = true;
+  }
+  for (int f = 0; f < n_frames; ++f) ST_CHECK_HIP(hipGraphLaunch(s->graph_exec, st));
+  return SMOLTTS_OK;
+}
+
+int smoltts_session_outputs(SmolttsSession* s, int32_t** codes_dev, int32_t** n_frames_dev, int32_t** done_dev,
+                            float** margin_dev) {
+  ST_REQUIRE(s, SMOLTTS_E_INVALID, "session_outputs: null session");
+  if (codes_dev) *codes_dev = s->codes;
+  if (n_frames_dev) *n_frames_dev = s->frames;
+  if (done_dev) *done_dev = s->done;
+  if (margin_dev) *margin_dev = s->margin;
+  return SMOLTTS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,341 @@
+// Mimi decoder engine: codes -> 24 kHz PCM, chunk-streaming (state carried across calls).
+//
+// Reference chain MimiModel._decode_frame (mlx_inference/src/smoltts_mlx/codec/mimi.py:73-104):
+//   quantizer.decode (codec/rvq.py:179-186) -> upsample (codec/conv.py:232-282) ->
+//   decoder_transformer (codec/transformer.py:134-150) -> SEANet decoder (codec/seanet.py:99-161).
+// All activations are channel-last fp32 [slot][time][channels]; every Linear / Conv1d /
+// ConvTranspose1d runs on the fp32 matrix-core GEMM (gemm.hip) with the causal padding expressed as
+// halo rows in front of each conv input buffer: a stride-1 conv of k taps reads the k consecutive
+// rows ending at t as one K = k*Cin contraction, a ConvTranspose1d (k = 2*stride) reads rows
+// (t-1, t) and produces its `stride` output rows at once (N = stride*Cout), which lands directly
+// in channel-last order.  After a chunk the last halo rows are shifted to the front, so decoding
+// F frames in chunks == decoding them at once == MimiModel.decode.  (The reference's own
+// decode_step re-runs the upsample statelessly, mimi.py:77, and therefore differs from its batch
+// decode; this engine carries the upsample tap overlap instead.)
+#include <string.h>
+
+#include <new>
+
+#include "common.h"
+
+using namespace smoltts;
+
+namespace {
+constexpr int D = 512, HEADS = 8, FF = 2048, NCONV = 14, NBUF = 14;
+constexpr int SAMPLES = 1920;
+// buffer i feeds conv i (i < 13); channels, halo rows and rows per frame of each conv input
+// conv order: conv0 | convT1 res1.c3 res1.c1 | convT2 ... | convT4 res4.c3 res4.c1 | final
+constexpr int BUF_C[NBUF] = {512, 1024, 512, 256, 512, 256, 128, 256, 128, 64, 128, 64, 32, 64};
+constexpr int BUF_HALO[NBUF] = {6, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 2};
+constexpr int BUF_RPF[NBUF] = {2, 2, 16, 16, 16, 96, 96, 96, 480, 480, 480, 1920, 1920, 1920};
+// buffer index feeding each conv (conv c reads BUF[c]; writes BUF[c+1], the last writes pcm)
+}  // namespace
+
+struct SmolttsMimi {
+  SmolttsMimiConfig cfg;
+  SmolttsMimiWeights w;
+  const char* arena;
+  size_t arena_bytes;
+};
+
+struct SmolttsMimiSession {
+  SmolttsMimi* m;
+  int B, chunk;
+  float* carry[2];   // [B][512] upsample carry (previous frame's RVQ embedding), double-buffered
+  float *tx, *tn, *tq, *ta, *th;  // transformer rows [B*2*chunk][512|512|512|512|2048]
+  float *kc, *vc;    // [n_layers][B][8][max_positions][64]
+  int *row_pos, *row_slot;  // [B*2*chunk]
+  float* buf[NBUF];
+  size_t buf_bstride[NBUF];  // floats per slot
+  size_t halo_total;         // bytes of everything that reset must zero: tracked via pointers below
+  char* zero_begin;
+  size_t zero_bytes;
+  int positions;     // transformer positions consumed so far (uniform over slots)
+  int parity;
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct Carver {
+  char* base;
+  size_t off;
+  template <typename T>
+  T* take(size_t n) {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off = align_up(off + n * sizeof(T));
+    return p;
+  }
+};
+
+void carve(SmolttsMimiSession* s, char* base, size_t* total) {
+  Carver cv{base, 0};
+  const size_t B = s->B, F = s->chunk, R = B * 2 * F;
+  const SmolttsMimiConfig& c = s->m->cfg;
+  // --- state that smoltts_mimi_reset zeroes (contiguous)
+  const size_t z0 = cv.off;
+  s->carry[0] = cv.take<float>(B * D);
+  s->carry[1] = cv.take<float>(B * D);
+  for (int i = 0; i < NBUF; ++i) {
+    s->buf_bstride[i] = (size_t)(BUF_HALO[i] + BUF_RPF[i] * F) * BUF_C[i];
+    s->buf[i] = cv.take<float>(B * s->buf_bstride[i]);
+  }
+  s->zero_begin = base ? base + z0 : nullptr;
+  s->zero_bytes = cv.off - z0;
+  // --- scratch / caches (need no zeroing: only positions < `positions` are ever read)
+  s->tx = cv.take<float>(R * D);
+  s->tn = cv.take<float>(R * D);
+  s->tq = cv.take<float>(R * D);
+  s->ta = cv.take<float>(R * D);
+  s->th = cv.take<float>(R * FF);
+  const size_t kv = (size_t)c.n_layers * B * HEADS * c.max_positions * 64;
+  s->kc = cv.take<float>(kv);
+  s->vc = cv.take<float>(kv);
+  s->row_pos = cv.take<int>(R);
+  s->row_slot = cv.take<int>(R);
+  *total = cv.off;
+}
+
+// e[b][f] = sum_q table[q][code[b][f][q]]  (rvq.py:118-131,179-186 with output_proj folded in),
+// then the depthwise ConvTranspose1d k=4 s=2 (conv.py:271-282):
+// out[2f + r][c] = e[f][c] * w[r][c] + e[f-1][c] * w[r+2][c], e[-1] = carry.
+__global__ __launch_bounds__(128) void rvq_upsample_kernel(const int* codes, long codes_stride, int frame_stride, int code_offset,
+                                                           int nq, int n_frames, const float* table, const float* upw,
+                                                           const float* carry_in, float* carry_out, float* tx) {
+  const int f = blockIdx.x, b = blockIdx.y, c = threadIdx.x * 4;
+  auto embed = [&](int ff) {
+    const int* cd = codes + (long)b * codes_stride + (long)ff * frame_stride + code_offset;
+    float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < nq; ++q) {
+      int code = cd[q];
+      code = code < 0 ? 0 : (code > 2047 ? 2047 : code);
+      const float4 t = *reinterpret_cast<const float4*>(table + ((long)q * 2048 + code) * D + c);
+      e.x += t.x; e.y += t.y; e.z += t.z; e.w += t.w;
+    }
+    return e;
+  };
+  const float4 cur = embed(f);
+  const float4 prev = f > 0 ? embed(f - 1) : *reinterpret_cast<const float4*>(carry_in + (long)b * D + c);
+  const float4 w0 = *reinterpret_cast<const float4*>(upw + 0 * D + c), w1 = *reinterpret_cast<const float4*>(upw + 1 * D + c);
+  const float4 w2 = *reinterpret_cast<const float4*>(upw + 2 * D + c), w3 = *reinterpret_cast<const float4*>(upw + 3 * D + c);
+  float* o = tx + ((long)b * 2 * n_frames + 2 * f) * D + c;
+  *reinterpret_cast<float4*>(o) = make_float4(cur.x * w0.x + prev.x * w2.x, cur.y * w0.y + prev.y * w2.y,
+                                              cur.z * w0.z + prev.z * w2.z, cur.w * w0.w + prev.w * w2.w);
+  *reinterpret_cast<float4*>(o + D) = make_float4(cur.x * w1.x + prev.x * w3.x, cur.y * w1.y + prev.y * w3.y,
+                                                  cur.z * w1.z + prev.z * w3.z, cur.w * w1.w + prev.w * w3.w);
+  if (f == n_frames - 1) *reinterpret_cast<float4*>(carry_out + (long)b * D + c) = cur;
+}
+
+__global__ void mimi_rows_kernel(int n_rows, int rows_per_slot, int pos0, int* row_pos, int* row_slot) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_rows) return;
+  const int b = m / rows_per_slot;
+  row_slot[m] = b;
+  row_pos[m] = pos0 + (m - b * rows_per_slot);
+}
+
+// Shift the last `halo` rows of every conv input buffer to its front (streaming carry).
+struct HaloDesc {
+  float* buf[NBUF];
+  long bstride[NBUF];
+  int C[NBUF], halo[NBUF], T[NBUF];
+};
+__global__ __launch_bounds__(256) void halo_shift_kernel(HaloDesc d) {
+  extern __shared__ float sh[];
+  const int b = blockIdx.x, i = blockIdx.y;
+  const int n = d.halo[i] * d.C[i];
+  if (n == 0) return;
+  float* base = d.buf[i] + (long)b * d.bstride[i];
+  const float* src = base + (long)d.T[i] * d.C[i];  // rows [T, T+halo) == the last halo rows of halo+data
+  for (int j = threadIdx.x; j < n; j += 256) sh[j] = src[j];
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += 256) base[j] = sh[j];
+}
+
+SmolttsGemmArgs gemm_f32(const void* w, const float* x, long ldx, int M, int N, int K) {
+  SmolttsGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.w_dev = w; a.w_is_fp32 = 1; a.x_dev = x; a.ldx = ldx; a.M = M; a.N = N; a.K = K;
+  return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smoltts_mimi_create(const SmolttsMimiConfig* cfg, const SmolttsMimiWeights* offsets, const void* arena_dev,
+                        size_t arena_bytes, SmolttsMimi** out) {
+  ST_REQUIRE(cfg && offsets && arena_dev && out, SMOLTTS_E_INVALID, "mimi_create: null argument");
+  ST_REQUIRE(cfg->num_codebooks >= 1 && cfg->num_codebooks <= 32 && cfg->n_layers >= 1 && cfg->n_layers <= SMOLTTS_MIMI_MAX_LAYERS &&
+                 cfg->max_positions >= 2 && cfg->window >= 0,
+             SMOLTTS_E_INVALID, "mimi_create: bad config");
+  for (int i = 0; i < NCONV; ++i) {
+    const SmolttsMimiConv& cv = offsets->convs[i];
+    ST_REQUIRE(cv.cin == BUF_C[i] && (i + 1 == NCONV ? cv.cout == 1 : (cv.transposed ? cv.cout : cv.cout) == BUF_C[i + 1]) &&
+                   (cv.transposed ? (cv.k == 2 * cv.stride && BUF_HALO[i] == 1) : (cv.stride == 1 && BUF_HALO[i] == cv.k - 1)) && cv.w % 16 == 0 && cv.b % 16 == 0 && cv.w < arena_bytes && cv.b < arena_bytes,
+               SMOLTTS_E_INVALID, "mimi_create: conv %d descriptor inconsistent (cin=%d)", i, cv.cin);
+  }
+  ST_REQUIRE(offsets->rvq_table + (size_t)cfg->num_codebooks * 2048 * D * 4 <= arena_bytes &&
+                 offsets->rope + (size_t)cfg->max_positions * 64 * 4 <= arena_bytes,
+             SMOLTTS_E_INVALID, "mimi_create: table offsets outside the arena");
+  SmolttsMimi* m = new (std::nothrow) SmolttsMimi;
+  ST_REQUIRE(m, SMOLTTS_E_INVALID, "mimi_create: out of host memory");
+  m->cfg = *cfg; m->w = *offsets; m->arena = (const char*)arena_dev; m->arena_bytes = arena_bytes;
+  *out = m;
+  return SMOLTTS_OK;
+}
+
+void smoltts_mimi_destroy(SmolttsMimi* m) { delete m; }
+
+size_t smoltts_mimi_slab_bytes(const SmolttsMimi* m, int32_t max_batch, int32_t max_chunk_frames) {
+  if (!m || max_batch <= 0 || max_chunk_frames <= 0) return 0;
+  SmolttsMimiSession tmp;
+  memset(&tmp, 0, sizeof(tmp));
+  tmp.m = const_cast<SmolttsMimi*>(m);
+  tmp.B = max_batch; tmp.chunk = max_chunk_frames;
+  size_t total = 0;
+  carve(&tmp, nullptr, &total);
+  return total;
+}
+
+int smoltts_mimi_session_create(SmolttsMimi* m, void* slab_dev, size_t slab_bytes, int32_t max_batch,
+                                int32_t max_chunk_frames, SmolttsMimiSession** out) {
+  ST_REQUIRE(m && slab_dev && out && max_batch > 0 && max_chunk_frames > 0, SMOLTTS_E_INVALID, "mimi_session_create: bad argument");
+  ST_REQUIRE(((uintptr_t)slab_dev & 255) == 0, SMOLTTS_E_INVALID, "mimi_session_create: slab must be 256-byte aligned");
+  ST_REQUIRE(2 * max_chunk_frames <= m->cfg.max_positions, SMOLTTS_E_CAPACITY, "mimi_session_create: chunk exceeds max_positions");
+  const size_t need = smoltts_mimi_slab_bytes(m, max_batch, max_chunk_frames);
+  ST_REQUIRE(slab_bytes >= need, SMOLTTS_E_CAPACITY, "mimi_session_create: slab has %zu bytes, %zu needed", slab_bytes, need);
+  SmolttsMimiSession* s = new (std::nothrow) SmolttsMimiSession;
+  ST_REQUIRE(s, SMOLTTS_E_INVALID, "mimi_session_create: out of host memory");
+  memset(s, 0, sizeof(*s));
+  s->m = m; s->B = max_batch; s->chunk = max_chunk_frames;
+  size_t total = 0;
+  carve(s, (char*)slab_dev, &total);
+  if (hipMemset(s->zero_begin, 0, s->zero_bytes) != hipSuccess) {
+    delete s;
+    set_error("mimi_session_create: hipMemset failed");
+    return SMOLTTS_E_HIP;
+  }
+  *out = s;
+  return SMOLTTS_OK;
+}
+
+void smoltts_mimi_session_destroy(SmolttsMimiSession* s) { delete s; }
+
+int smoltts_mimi_reset(SmolttsMimiSession* s, void* stream) {
+  ST_REQUIRE(s, SMOLTTS_E_INVALID, "mimi_reset: null session");
+  ST_CHECK_HIP(hipMemsetAsync(s->zero_begin, 0, s->zero_bytes, (hipStream_t)stream));
+  s->positions = 0;
+  s->parity = 0;
+  return SMOLTTS_OK;
+}
+
+int smoltts_mimi_decode_chunk(SmolttsMimiSession* s, const int32_t* codes_dev, int64_t codes_stride, int32_t frame_stride,
+                              int32_t code_offset, int32_t batch, int32_t n_frames, float* pcm_dev, int64_t pcm_stride,
+                              void* stream) {
+  ST_REQUIRE(s && codes_dev && pcm_dev, SMOLTTS_E_INVALID, "mimi_decode_chunk: null argument");
+  ST_REQUIRE(batch > 0 && batch <= s->B && n_frames > 0 && n_frames <= s->chunk, SMOLTTS_E_CAPACITY,
+             "mimi_decode_chunk: batch=%d frames=%d exceed the session (%d, %d)", batch, n_frames, s->B, s->chunk);
+  const SmolttsMimi* m = s->m;
+  const SmolttsMimiConfig& c = m->cfg;
+  ST_REQUIRE(s->positions + 2 * n_frames <= c.max_positions, SMOLTTS_E_CAPACITY,
+             "mimi_decode_chunk: %d positions exceed max_positions=%d", s->positions + 2 * n_frames, c.max_positions);
+  ST_REQUIRE(frame_stride >= c.num_codebooks + code_offset && code_offset >= 0 && pcm_stride >= (int64_t)SAMPLES * n_frames &&
+                 pcm_stride % 4 == 0 && ((uintptr_t)pcm_dev & 15) == 0,
+             SMOLTTS_E_INVALID, "mimi_decode_chunk: bad strides");
+  hipStream_t st = (hipStream_t)stream;
+  const char* A = m->arena;
+  const int F = n_frames, Tt = 2 * F, R = batch * Tt;
+
+  // 1. RVQ gather (+ folded output_proj) and depthwise upsample -> transformer rows tx[b][2F][512]
+  hipLaunchKernelGGL(rvq_upsample_kernel, dim3(F, batch), dim3(128), 0, st, codes_dev, (long)codes_stride, frame_stride, code_offset,
+                     c.num_codebooks, F, (const float*)(A + m->w.rvq_table), (const float*)(A + m->w.upsample_w),
+                     s->carry[s->parity], s->carry[s->parity ^ 1], s->tx);
+  ST_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(mimi_rows_kernel, dim3((R + 255) / 256), dim3(256), 0, st, R, Tt, s->positions, s->row_pos, s->row_slot);
+  ST_CHECK_HIP(hipGetLastError());
+
+  // 2. decoder transformer (transformer.py:109-131)
+  const size_t l_stride = (size_t)s->B * HEADS * c.max_positions * 64;
+  for (int l = 0; l < c.n_layers; ++l) {
+    const SmolttsMimiLayerWeights& lw = m->w.layers[l];
+    ST_TRY(launch_layernorm(s->tx, (const float*)(A + lw.ln1_w), (const float*)(A + lw.ln1_b), R, D, 1e-5f, s->tn, st));
+    {
+      SmolttsGemmArgs a = gemm_f32(A + lw.wqkv, s->tn, D, R, 3 * D, D);
+      a.epilogue = SMOLTTS_EPI_QKV_ROPE; a.out_dev = s->tq; a.ldo = D;
+      a.rope_dev = (const float*)(A + m->w.rope); a.row_pos_dev = s->row_pos; a.row_slot_dev = s->row_slot;
+      a.k_cache_dev = s->kc + l * l_stride; a.v_cache_dev = s->vc + l * l_stride;
+      a.n_q_heads = HEADS; a.n_kv_heads = HEADS; a.cache_len = c.max_positions;
+      ST_TRY(launch_gemm(a, st));
+    }
+    ST_TRY(launch_attention(s->tq, s->kc + l * l_stride, s->vc + l * l_stride, s->row_pos, s->row_slot, R, HEADS, HEADS,
+                            c.max_positions, c.window, s->ta, st));
+    {
+      SmolttsGemmArgs a = gemm_f32(A + lw.wo, s->ta, D, R, D, D);
+      a.epilogue = SMOLTTS_EPI_SCALE_RESID; a.scale_dev = (const float*)(A + lw.ls1);
+      a.resid_dev = s->tx; a.out_dev = s->tx; a.ldo = D;
+      ST_TRY(launch_gemm(a, st));
+    }
+    ST_TRY(launch_layernorm(s->tx, (const float*)(A + lw.ln2_w), (const float*)(A + lw.ln2_b), R, D, 1e-5f, s->tn, st));
+    {
+      SmolttsGemmArgs a = gemm_f32(A + lw.fc1, s->tn, D, R, FF, D);
+      a.epilogue = SMOLTTS_EPI_GELU; a.out_dev = s->th; a.ldo = FF;
+      ST_TRY(launch_gemm(a, st));
+    }
+    {
+      SmolttsGemmArgs a = gemm_f32(A + lw.fc2, s->th, FF, R, D, FF);
+      a.epilogue = SMOLTTS_EPI_SCALE_RESID; a.scale_dev = (const float*)(A + lw.ls2);
+      a.resid_dev = s->tx; a.ldr = D; a.r_bstride = (int64_t)Tt * D; a.rows_per_batch = Tt;
+      a.x_bstride = (int64_t)Tt * FF;
+      if (l + 1 < c.n_layers) {
+        a.out_dev = s->tx; a.ldo = D; a.o_bstride = (int64_t)Tt * D;
+      } else {  // last layer: write straight into conv0's input buffer, behind its halo
+        a.out_dev = s->buf[0] + (size_t)BUF_HALO[0] * BUF_C[0]; a.ldo = D; a.o_bstride = (int64_t)s->buf_bstride[0];
+      }
+      ST_TRY(launch_gemm(a, st));
+    }
+  }
+
+  // 3. SEANet decoder (seanet.py:105-139) as 14 GEMMs over halo-prefixed channel-last buffers
+  for (int i = 0; i < NCONV; ++i) {
+    const SmolttsMimiConv& cv = m->w.convs[i];
+    const int Tin = BUF_RPF[i] * F;
+    const int K = cv.transposed ? 2 * cv.cin : cv.k * cv.cin;
+    const int N = cv.transposed ? cv.stride * cv.cout : cv.cout;
+    SmolttsGemmArgs a = gemm_f32(A + cv.w, s->buf[i], cv.cin, batch * Tin, N, K);
+    a.rows_per_batch = Tin; a.x_bstride = (int64_t)s->buf_bstride[i];
+    a.bias_dev = (const float*)(A + cv.b);
+    a.prologue = i == 0 ? SMOLTTS_PRO_NONE : SMOLTTS_PRO_ELU;
+    a.epilogue = SMOLTTS_EPI_STORE;
+    if (i + 1 < NCONV) {
+      a.out_dev = s->buf[i + 1] + (size_t)BUF_HALO[i + 1] * BUF_C[i + 1];
+      a.ldo = N; a.o_bstride = (int64_t)s->buf_bstride[i + 1];
+    } else {
+      a.out_dev = pcm_dev; a.ldo = 1; a.o_bstride = pcm_stride;
+    }
+    const bool res_c1 = i >= 3 && i <= 12 && (i % 3) == 0;  // second conv of a residual block: + block input
+    if (res_c1) {
+      a.epilogue = SMOLTTS_EPI_RESID;
+      a.resid_dev = s->buf[i - 1] + (size_t)BUF_HALO[i - 1] * BUF_C[i - 1];
+      a.ldr = BUF_C[i - 1]; a.r_bstride = (int64_t)s->buf_bstride[i - 1];
+    }
+    ST_TRY(launch_gemm(a, st));
+  }
+
+  // 4. streaming carry: last halo rows of every conv input buffer move to the front
+  {
+    HaloDesc d;
+    for (int i = 0; i < NBUF; ++i) {
+      d.buf[i] = s->buf[i]; d.bstride[i] = (long)s->buf_bstride[i];
+      d.C[i] = BUF_C[i]; d.halo[i] = BUF_HALO[i]; d.T[i] = BUF_RPF[i] * F;
+    }
+    hipLaunchKernelGGL(halo_shift_kernel, dim3(batch, NBUF), dim3(256), 6 * 512 * sizeof(float), st, d);
+    ST_CHECK_HIP(hipGetLastError());
+  }
+  s->positions += Tt;
+  s->parity ^= 1;
+  return SMOLTTS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,170 @@
+// Gather / reduce operators around the GEMMs: token embedding, greedy argmax (+ next-step
+// embedding gather), LayerNorm, row gather.  All are HBM/L2-bound byte movers: one workgroup per
+// row, 16-byte (fp32) / 8-byte (bf16x4) accesses per lane, fixed-order reductions.
+#include "common.h"
+
+namespace smoltts {
+
+// ------------------------------------------------------------------------------------ embed
+// x[r] = E_text[cols[r][0]] + keep * sum_k E_cb[cols[r][1+k] + cb_first_offset + k*codebook_size]
+// reference: BaseTransformer.embed (modeling/model/rq_transformer.py:205-221); MLX twin
+// lm/rq_transformer.py:150-170 (mask rule differs: mask_mode 1).
+__global__ __launch_bounds__(256) void embed_kernel(const int* cols, int n_code_rows, const uint16_t* text_emb,
+                                                    const uint16_t* cb_emb, int dim, int codebook_size,
+                                                    int cb_first_offset, int mask_mode, int sem_start, int sem_end,
+                                                    int text_rows, int cb_rows, float* x) {
+  const int r = blockIdx.x;
+  const int* c = cols + (long)r * (1 + n_code_rows);
+  int tok = c[0];
+  tok = tok < 0 ? 0 : (tok >= text_rows ? text_rows - 1 : tok);  // never read outside the table
+  const bool keep = mask_mode == 0 ? (c[1] != 0) : (tok >= sem_start && tok <= sem_end);
+  for (int d = threadIdx.x * 4; d < dim; d += blockDim.x * 4) {
+    const uint2 t = *reinterpret_cast<const uint2*>(text_emb + (long)tok * dim + d);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (keep) {
+      for (int k = 0; k < n_code_rows; ++k) {  // same summation order as vq_embeds.sum(dim=1)
+        long row = (long)c[1 + k] + cb_first_offset + (long)k * codebook_size;
+        row = row < 0 ? 0 : (row >= cb_rows ? cb_rows - 1 : row);
+        const uint2 e = *reinterpret_cast<const uint2*>(cb_emb + row * dim + d);
+        acc.x += bf16_lo(e.x); acc.y += bf16_hi(e.x); acc.z += bf16_lo(e.y); acc.w += bf16_hi(e.y);
+      }
+    }
+    *reinterpret_cast<float4*>(x + (long)r * dim + d) =
+        make_float4(bf16_lo(t.x) + acc.x, bf16_hi(t.x) + acc.y, bf16_lo(t.y) + acc.z, bf16_hi(t.y) + acc.w);
+  }
+}
+
+int launch_embed(const int32_t* cols, int n_rows, int n_code_rows, const void* text_emb, const void* cb_emb, int dim,
+                 int codebook_size, int cb_first_offset, int mask_mode, int sem_start, int sem_end, int text_rows,
+                 int cb_rows, float* x, hipStream_t stream) {
+  ST_REQUIRE(cols && text_emb && cb_emb && x && n_rows > 0 && dim % 4 == 0 && n_code_rows >= 1, SMOLTTS_E_INVALID,
+             "embed: bad arguments");
+  hipLaunchKernelGGL(embed_kernel, dim3(n_rows), dim3(256), 0, stream, cols, n_code_rows, (const uint16_t*)text_emb,
+                     (const uint16_t*)cb_emb, dim, codebook_size, cb_first_offset, mask_mode, sem_start, sem_end, text_rows, cb_rows, x);
+  ST_CHECK_HIP(hipGetLastError());
+  return SMOLTTS_OK;
+}
+
+// ------------------------------------------------------------------------------------ argmax
+// torch.argmax / mx.argmax semantics: index of the first maximal element.  Also tracks the
+// top-1/top-2 gap (parity diagnostics) and optionally gathers the next fast-step embedding
+// (lm/generate.py:134-140: fast_embeddings(code + i*codebook_size)).
+struct Top2 {
+  float v1;
+  int i1;
+  float v2;
+};
+__device__ __forceinline__ Top2 top2_merge(Top2 a, Top2 b) {
+  Top2 o;
+  const bool a_first = (a.v1 > b.v1) || (a.v1 == b.v1 && a.i1 < b.i1);
+  if (a_first) {
+    o.v1 = a.v1; o.i1 = a.i1; o.v2 = fmaxf(a.v2, b.v1);
+  } else {
+    o.v1 = b.v1; o.i1 = b.i1; o.v2 = fmaxf(b.v2, a.v1);
+  }
+  return o;
+}
+
+__global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int n_cols, long ld, int* ids, int ids_stride,
+                                                     float* margin, const int* margin_mask, const uint16_t* emb,
+                                                     int emb_row_offset, int dim, float* xnext) {
+  __shared__ Top2 sh[4];
+  __shared__ int s_id;
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = logits + (long)r * ld;
+  Top2 t{-INFINITY, 0x7fffffff, -INFINITY};
+  for (int j = tid; j < n_cols; j += 256) {
+    const float v = row[j];
+    if (v > t.v1) {  // strictly greater keeps the earliest index inside a thread (j ascending)
+      t.v2 = t.v1; t.v1 = v; t.i1 = j;
+    } else if (v > t.v2) {
+      t.v2 = v;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Top2 b;
+    b.v1 = __shfl_xor(t.v1, o); b.i1 = __shfl_xor(t.i1, o); b.v2 = __shfl_xor(t.v2, o);
+    t = top2_merge(t, b);
+  }
+  if (lane == 0) sh[wave] = t;
+  __syncthreads();
+  if (tid == 0) {
+    Top2 a = top2_merge(top2_merge(sh[0], sh[1]), top2_merge(sh[2], sh[3]));
+    if (a.i1 < 0 || a.i1 >= n_cols) a.i1 = 0;  // all-NaN row: stay inside the tables
+    ids[(long)r * ids_stride] = a.i1;
+    if (margin && (margin_mask == nullptr || margin_mask[r])) margin[r] = fminf(margin[r], a.v1 - a.v2);
+    s_id = a.i1;
+  }
+  if (emb == nullptr) return;
+  __syncthreads();
+  const long erow = (long)s_id + emb_row_offset;
+  for (int d = tid * 4; d < dim; d += 256 * 4) {
+    const uint2 e = *reinterpret_cast<const uint2*>(emb + erow * dim + d);
+    *reinterpret_cast<float4*>(xnext + (long)r * dim + d) = make_float4(bf16_lo(e.x), bf16_hi(e.x), bf16_lo(e.y), bf16_hi(e.y));
+  }
+}
+
+int launch_argmax(const float* logits, int n_rows, int n_cols, int64_t ld, int32_t* ids, int ids_stride, float* margin,
+                  const int32_t* margin_mask, const void* emb, int emb_row_offset, int dim, float* xnext,
+                  hipStream_t stream) {
+  ST_REQUIRE(logits && ids && n_rows > 0 && n_cols > 0, SMOLTTS_E_INVALID, "argmax: bad arguments");
+  ST_REQUIRE(emb == nullptr || (xnext && dim % 4 == 0), SMOLTTS_E_INVALID, "argmax: bad gather arguments");
+  hipLaunchKernelGGL(argmax_kernel, dim3(n_rows), dim3(256), 0, stream, logits, n_cols, (long)ld, ids, ids_stride, margin,
+                     margin_mask, (const uint16_t*)emb, emb_row_offset, dim, xnext);
+  ST_CHECK_HIP(hipGetLastError());
+  return SMOLTTS_OK;
+}
+
+// ------------------------------------------------------------------------------------ layernorm
+// nn.LayerNorm(d_model) with bias, eps 1e-5 (mlx_inference/.../codec/transformer.py:113-114).
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* w, const float* b, int dim, float eps,
+                                                        float* out) {
+  __shared__ float sh[8];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xr = x + (long)r * dim;
+  float s = 0.f;
+  for (int d = tid; d < dim; d += 256) s += xr[d];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) sh[wave] = s;
+  __syncthreads();
+  const float mean = (((sh[0] + sh[1]) + sh[2]) + sh[3]) / (float)dim;
+  float v = 0.f;
+  for (int d = tid; d < dim; d += 256) {
+    const float c = xr[d] - mean;
+    v = fmaf(c, c, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if (lane == 0) sh[4 + wave] = v;
+  __syncthreads();
+  const float var = (((sh[4] + sh[5]) + sh[6]) + sh[7]) / (float)dim;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  for (int d = tid; d < dim; d += 256) out[(long)r * dim + d] = (xr[d] - mean) * rstd * w[d] + b[d];
+}
+
+int launch_layernorm(const float* x, const float* w, const float* b, int n_rows, int dim, float eps, float* out,
+                     hipStream_t stream) {
+  ST_REQUIRE(x && w && b && out && n_rows > 0 && dim > 0, SMOLTTS_E_INVALID, "layernorm: bad arguments");
+  hipLaunchKernelGGL(layernorm_kernel, dim3(n_rows), dim3(256), 0, stream, x, w, b, dim, eps, out);
+  ST_CHECK_HIP(hipGetLastError());
+  return SMOLTTS_OK;
+}
+
+// ------------------------------------------------------------------------------------ row gather
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* src, const int* idx, int dim, float* dst) {
+  const int r = blockIdx.x;
+  const long s = idx[r];
+  for (int d = threadIdx.x * 4; d < dim; d += 256 * 4)
+    *reinterpret_cast<float4*>(dst + (long)r * dim + d) = *reinterpret_cast<const float4*>(src + s * dim + d);
+}
+
+int launch_gather_rows(const float* src, const int32_t* idx, int n, int dim, float* dst, hipStream_t stream) {
+  ST_REQUIRE(src && idx && dst && n > 0 && dim % 4 == 0, SMOLTTS_E_INVALID, "gather_rows: bad arguments");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(256), 0, stream, src, idx, dim, dst);
+  ST_CHECK_HIP(hipGetLastError());
+  return SMOLTTS_OK;
+}
+
+}  // namespace smoltts

@@ -1,0 +1,414 @@
+"""ctypes binding of ``libsmoltts_hip.so`` (include/smoltts_hip.h) and the thin Python objects
+around it.  PyTorch-ROCm is used only as a container for device memory and streams.
+
+There is no CPU fallback: ``load_library`` raises when the HIP library has not been built, and
+every wrapper raises ``SmolttsError`` on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .config import NumericsMode, RQTransformerModelArgs, TokenConfig
+from . import packing
+
+LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libsmoltts_hip.so"
+MAX_LAYERS, MAX_FAST_LAYERS, MIMI_MAX_LAYERS = 64, 16, 16
+
+
+class SmolttsError(RuntimeError):
+    pass
+
+
+# ------------------------------------------------------------------------------- C structs
+class BlockWeights(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("attn_norm", "wqkv", "wo", "ffn_norm", "w13", "w2")]
+
+
+class LMConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dim", "n_layer", "n_head", "n_kv_head", "inter",
+        "fast_dim", "n_fast_layer", "fast_n_head", "fast_n_kv_head", "fast_inter",
+        "vocab_size", "codebook_size", "num_codebooks", "n_fast", "duplicate_code_0", "depthwise_wte",
+        "has_fast_project_in", "embed_mask_mode", "semantic_start_id", "semantic_end_id", "im_end_id",
+        "max_seq_len")] + [("norm_eps", C.c_float)]
+
+
+class LMWeights(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "text_emb", "codebook_emb", "fast_emb", "norm", "head", "fast_norm", "fast_head",
+        "fast_head_step_stride", "fast_proj_w", "fast_proj_b", "rope", "fast_rope")] + [
+        ("layers", BlockWeights * MAX_LAYERS), ("fast_layers", BlockWeights * MAX_FAST_LAYERS)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("w_dev", C.c_void_p), ("w_is_fp32", C.c_int32), ("x_dev", C.c_void_p), ("ldx", C.c_int64),
+        ("x_bstride", C.c_int64), ("rows_per_batch", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
+        ("K", C.c_int32), ("prologue", C.c_int32), ("epilogue", C.c_int32), ("gamma_dev", C.c_void_p),
+        ("eps", C.c_float), ("bias_dev", C.c_void_p), ("scale_dev", C.c_void_p), ("resid_dev", C.c_void_p),
+        ("ldr", C.c_int64), ("r_bstride", C.c_int64), ("out_dev", C.c_void_p), ("ldo", C.c_int64), ("o_bstride", C.c_int64), ("rope_dev", C.c_void_p),
+        ("row_pos_dev", C.c_void_p), ("row_slot_dev", C.c_void_p), ("k_cache_dev", C.c_void_p),
+        ("v_cache_dev", C.c_void_p), ("n_q_heads", C.c_int32), ("n_kv_heads", C.c_int32), ("cache_len", C.c_int32),
+    ]
+
+
+class MimiLayerWeights(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("ln1_w", "ln1_b", "wqkv", "wo", "ls1", "ln2_w", "ln2_b", "fc1", "fc2", "ls2")]
+
+
+class MimiConv(C.Structure):
+    _fields_ = [("w", C.c_uint64), ("b", C.c_uint64)] + [(n, C.c_int32) for n in ("cin", "cout", "k", "stride", "transposed")]
+
+
+class MimiConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("num_codebooks", "n_layers", "window", "max_positions")]
+
+
+class MimiWeights(C.Structure):
+    _fields_ = [("rvq_table", C.c_uint64), ("upsample_w", C.c_uint64), ("rope", C.c_uint64),
+                ("layers", MimiLayerWeights * MIMI_MAX_LAYERS), ("convs", MimiConv * 14)]
+
+
+PRO_NONE, PRO_RMSNORM, PRO_ELU = 0, 1, 2
+EPI_STORE, EPI_RESID, EPI_SWIGLU, EPI_GELU, EPI_SCALE_RESID, EPI_QKV_ROPE = range(6)
+
+_lib = None
+
+_EXPORTS = [
+    "smoltts_last_error", "smoltts_abi_version", "smoltts_engine_create", "smoltts_engine_destroy",
+    "smoltts_session_slab_bytes", "smoltts_session_create", "smoltts_session_destroy", "smoltts_lm_prefill",
+    "smoltts_lm_decode", "smoltts_session_outputs", "smoltts_mimi_create", "smoltts_mimi_destroy",
+    "smoltts_mimi_slab_bytes", "smoltts_mimi_session_create", "smoltts_mimi_session_destroy", "smoltts_mimi_reset",
+    "smoltts_mimi_decode_chunk", "smoltts_k_gemm", "smoltts_k_attention", "smoltts_k_embed", "smoltts_k_argmax",
+    "smoltts_k_layernorm",
+]
+
+
+def exported_symbols() -> List[str]:
+    return list(_EXPORTS)
+
+
+def load_library(path: Optional[Path] = None):
+    """dlopen the in-tree HIP library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path is not None else LIB_PATH
+    if not p.exists():
+        raise SmolttsError(
+            f"{p} not found: build it with `python -m smoltts_amd.build` (hipcc, gfx950). "
+            "smoltts_amd has no CPU fallback.")
+    lib = C.CDLL(str(p))
+    lib.smoltts_last_error.restype = C.c_char_p
+    lib.smoltts_session_slab_bytes.restype = C.c_size_t
+    lib.smoltts_session_slab_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.smoltts_mimi_slab_bytes.restype = C.c_size_t
+    lib.smoltts_mimi_slab_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.smoltts_engine_create.argtypes = [C.POINTER(LMConfig), C.POINTER(LMWeights), C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.smoltts_engine_destroy.argtypes = [C.c_void_p]
+    lib.smoltts_engine_destroy.restype = None
+    lib.smoltts_session_create.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.smoltts_session_destroy.argtypes = [C.c_void_p]
+    lib.smoltts_session_destroy.restype = None
+    lib.smoltts_lm_prefill.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    lib.smoltts_lm_decode.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.smoltts_session_outputs.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 4
+    lib.smoltts_mimi_create.argtypes = [C.POINTER(MimiConfig), C.POINTER(MimiWeights), C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.smoltts_mimi_destroy.argtypes = [C.c_void_p]
+    lib.smoltts_mimi_destroy.restype = None
+    lib.smoltts_mimi_session_create.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.smoltts_mimi_session_destroy.argtypes = [C.c_void_p]
+    lib.smoltts_mimi_session_destroy.restype = None
+    lib.smoltts_mimi_reset.argtypes = [C.c_void_p, C.c_void_p]
+    lib.smoltts_mimi_decode_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.smoltts_k_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
+    lib.smoltts_k_attention.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p, C.c_void_p]
+    lib.smoltts_k_embed.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]
+    lib.smoltts_k_argmax.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.smoltts_k_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
+    if lib.smoltts_abi_version() != 1:
+        raise SmolttsError("libsmoltts_hip.so ABI version mismatch")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = load_library().smoltts_last_error().decode(errors="replace")
+        raise SmolttsError(f"{what} failed ({status}): {msg}")
+
+
+def _require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise SmolttsError("no HIP device visible; smoltts_amd runs on MI355X only (no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def current_stream_ptr() -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else int(t.data_ptr())
+
+
+def _alloc_slab(nbytes: int, device) -> torch.Tensor:
+    slab = torch.zeros(nbytes + 256, dtype=torch.uint8, device=device)
+    shift = (-slab.data_ptr()) % 256
+    return slab[shift: shift + nbytes]
+
+
+# ------------------------------------------------------------------------------- LM engine
+def lm_config_struct(cfg: RQTransformerModelArgs, tok: TokenConfig, numerics: NumericsMode) -> LMConfig:
+    c = LMConfig()
+    c.dim, c.n_layer, c.n_head, c.n_kv_head, c.inter = cfg.dim, cfg.n_layer, cfg.n_head, cfg.n_local_heads, cfg.intermediate_size
+    c.fast_dim, c.n_fast_layer, c.fast_n_head = cfg.fast_dim, cfg.n_fast_layer, cfg.fast_n_head
+    c.fast_n_kv_head, c.fast_inter = cfg.fast_n_local_heads, cfg.fast_intermediate_size
+    c.vocab_size, c.codebook_size, c.num_codebooks = cfg.vocab_size, cfg.codebook_size, cfg.num_codebooks
+    c.n_fast = cfg.max_fast_seqlen
+    c.duplicate_code_0 = int(bool(cfg.duplicate_code_0))
+    c.depthwise_wte = int(bool(cfg.depthwise_wte))
+    c.has_fast_project_in = int(cfg.fast_dim != cfg.dim)
+    c.embed_mask_mode = 0 if numerics.embed_mask == "torch" else 1
+    c.semantic_start_id = tok.semantic_start_id
+    c.semantic_end_id = tok.semantic_end_id if tok.semantic_end_id is not None else tok.semantic_start_id
+    c.im_end_id = tok.im_end_id
+    c.max_seq_len = cfg.max_seq_len
+    c.norm_eps = cfg.norm_eps
+    return c
+
+
+def _fill_block(dst: BlockWeights, src: Dict[str, int]) -> None:
+    for k, v in src.items():
+        setattr(dst, k, v)
+
+
+class LMEngine:
+    """Immutable model on one GPU: packed weight arena + ``SmolttsEngine`` handle."""
+
+    def __init__(self, cfg: RQTransformerModelArgs, state: Dict[str, torch.Tensor], token_config: TokenConfig,
+                 numerics: Optional[NumericsMode] = None, arena: Optional[torch.Tensor] = None, offsets=None):
+        cfg.validate_for_engine()
+        self.lib = load_library()
+        self.device = _require_gpu()
+        self.cfg, self.token_config = cfg, token_config
+        self.numerics = numerics or NumericsMode.torch_reference()
+        if arena is None:
+            arena, offsets = packing.pack_lm(cfg, state, self.numerics)
+        self.offsets = offsets
+        self.arena = arena.to(self.device) if arena.device != self.device else arena
+        self.c_cfg = lm_config_struct(cfg, token_config, self.numerics)
+        w = LMWeights()
+        for k in ("text_emb", "codebook_emb", "fast_emb", "norm", "head", "fast_norm", "fast_head",
+                  "fast_head_step_stride", "fast_proj_w", "fast_proj_b", "rope", "fast_rope"):
+            setattr(w, k, offsets[k])
+        for i, b in enumerate(offsets["layers"]):
+            _fill_block(w.layers[i], b)
+        for i, b in enumerate(offsets["fast_layers"]):
+            _fill_block(w.fast_layers[i], b)
+        self.c_w = w
+        h = C.c_void_p()
+        check(self.lib.smoltts_engine_create(C.byref(self.c_cfg), C.byref(w), dptr(self.arena), self.arena.numel(), C.byref(h)),
+              "smoltts_engine_create")
+        self.handle = h
+
+    @property
+    def grid_height(self) -> int:
+        return 1 + self.cfg.max_fast_seqlen
+
+    def weight_bytes(self) -> int:
+        return int(self.arena.numel())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.smoltts_engine_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LMSession:
+    """B utterance slots (KV caches + device-side frame loop state) inside one device slab."""
+
+    def __init__(self, engine: LMEngine, max_batch: int, max_seq: Optional[int] = None, max_rows: int = 4096,
+                 max_frames: int = 1025):
+        self.engine, self.lib = engine, engine.lib
+        self.B = max_batch
+        self.max_seq = max_seq or engine.cfg.max_seq_len
+        self.max_rows = max(max_rows, max_batch)
+        self.max_frames = max_frames
+        self.H = engine.grid_height
+        need = self.lib.smoltts_session_slab_bytes(engine.handle, self.B, self.max_seq, self.max_rows, self.max_frames)
+        if need == 0:
+            raise SmolttsError("smoltts_session_slab_bytes returned 0 (bad sizes)")
+        self.slab = _alloc_slab(need, engine.device)
+        h = C.c_void_p()
+        check(self.lib.smoltts_session_create(engine.handle, dptr(self.slab), need, self.B, self.max_seq, self.max_rows,
+                                              self.max_frames, C.byref(h)), "smoltts_session_create")
+        self.handle = h
+        ptrs = [C.c_void_p() for _ in range(4)]
+        check(self.lib.smoltts_session_outputs(h, *[C.byref(p) for p in ptrs]), "smoltts_session_outputs")
+        base = self.slab.data_ptr()
+
+        def view(p, nbytes, dtype, shape):
+            o = p.value - base
+            return self.slab[o: o + nbytes].view(dtype).view(*shape)
+
+        self.codes = view(ptrs[0], self.B * self.max_frames * self.H * 4, torch.int32, (self.B, self.max_frames, self.H))
+        self.n_frames = view(ptrs[1], self.B * 4, torch.int32, (self.B,))
+        self.done = view(ptrs[2], self.B * 4, torch.int32, (self.B,))
+        self.margin = view(ptrs[3], self.B * 4, torch.float32, (self.B,))
+        self._keep = None
+
+    def prefill(self, prompts: Sequence[np.ndarray], slots: Optional[Sequence[int]] = None, stop_on_eos: bool = True) -> None:
+        """prompts: one ``(1 + n_fast, T_b)`` int grid per utterance; emits frame 0 of each slot."""
+        slots = list(range(len(prompts))) if slots is None else list(slots)
+        if len(slots) != len(prompts) or len(set(slots)) != len(slots):
+            raise ValueError("slots must be distinct and match prompts")
+        cfg = self.engine.cfg
+        cols, rslot, rpos, last = [], [], [], []
+        n = 0
+        for g, sl in zip(prompts, slots):
+            g = np.asarray(g)
+            if g.ndim != 2 or g.shape[0] != self.H or g.shape[1] < 1:
+                raise ValueError(f"prompt grid must be ({self.H}, T>=1), got {g.shape}")
+            T = g.shape[1]
+            if T + 1 > self.max_seq:
+                raise SmolttsError(f"prompt of {T} tokens does not fit max_seq={self.max_seq}")
+            if g[0].min() < 0 or g[0].max() >= cfg.vocab_size or g[1:].min() < 0 or g[1:].max() >= cfg.codebook_size:
+                raise ValueError("prompt ids out of range")
+            cols.append(np.ascontiguousarray(g.T.astype(np.int32)))
+            rslot.append(np.full(T, sl, np.int32))
+            rpos.append(np.arange(T, dtype=np.int32))
+            n += T
+            last.append(n - 1)
+        if n > self.max_rows:
+            raise SmolttsError(f"{n} prompt rows exceed the session's max_rows={self.max_rows}")
+        dev = self.engine.device
+        grid_d = torch.from_numpy(np.concatenate(cols)).to(dev)
+        rslot_d = torch.from_numpy(np.concatenate(rslot)).to(dev)
+        rpos_d = torch.from_numpy(np.concatenate(rpos)).to(dev)
+        slots_h = (C.c_int32 * len(slots))(*slots)
+        last_h = (C.c_int32 * len(slots))(*last)
+        self._keep = (grid_d, rslot_d, rpos_d)  # alive until the stream has consumed them
+        check(self.lib.smoltts_lm_prefill(self.handle, dptr(grid_d), dptr(rslot_d), dptr(rpos_d), n, slots_h, last_h,
+                                          len(slots), int(stop_on_eos), current_stream_ptr()), "smoltts_lm_prefill")
+
+    def decode(self, n_frames: int) -> None:
+        check(self.lib.smoltts_lm_decode(self.handle, int(n_frames), current_stream_ptr()), "smoltts_lm_decode")
+
+    def fetch(self):
+        """Synchronise and return (codes [B, max_frames, H] int32, n_frames [B], done [B], margin [B]) on the host."""
+        torch.cuda.current_stream().synchronize()
+        return (self.codes.cpu().numpy(), self.n_frames.cpu().numpy(), self.done.cpu().numpy(), self.margin.cpu().numpy())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            torch.cuda.synchronize()
+            self.lib.smoltts_session_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------- Mimi engine
+class MimiEngine:
+    def __init__(self, state: Dict[str, torch.Tensor], num_codebooks: int = 8, window: int = 0, max_positions: int = 4096):
+        self.lib = load_library()
+        self.device = _require_gpu()
+        arena, off = packing.pack_mimi(state, num_codebooks, max_positions)
+        self.arena = arena.to(self.device)
+        self.num_codebooks = num_codebooks
+        cfg = MimiConfig(num_codebooks, off["n_layers"], window, max_positions)
+        w = MimiWeights()
+        w.rvq_table, w.upsample_w, w.rope = off["rvq_table"], off["upsample_w"], off["rope"]
+        for i, l in enumerate(off["layers"]):
+            for k, v in l.items():
+                setattr(w.layers[i], k, v)
+        for i, cv in enumerate(off["convs"]):
+            for k, v in cv.items():
+                setattr(w.convs[i], k, v)
+        self.c_cfg, self.c_w = cfg, w
+        h = C.c_void_p()
+        check(self.lib.smoltts_mimi_create(C.byref(cfg), C.byref(w), dptr(self.arena), self.arena.numel(), C.byref(h)),
+              "smoltts_mimi_create")
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.smoltts_mimi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MimiSession:
+    """Streaming Mimi decode state for ``max_batch`` slots; ``decode`` consumes frames chunk-wise."""
+
+    SAMPLES_PER_FRAME = 1920
+
+    def __init__(self, engine: MimiEngine, max_batch: int, max_chunk_frames: int = 8):
+        self.engine, self.lib = engine, engine.lib
+        self.B, self.chunk = max_batch, max_chunk_frames
+        need = self.lib.smoltts_mimi_slab_bytes(engine.handle, max_batch, max_chunk_frames)
+        if need == 0:
+            raise SmolttsError("smoltts_mimi_slab_bytes returned 0 (bad sizes)")
+        self.slab = _alloc_slab(need, engine.device)
+        h = C.c_void_p()
+        check(self.lib.smoltts_mimi_session_create(engine.handle, dptr(self.slab), need, max_batch, max_chunk_frames, C.byref(h)),
+              "smoltts_mimi_session_create")
+        self.handle = h
+
+    def reset(self) -> None:
+        check(self.lib.smoltts_mimi_reset(self.handle, current_stream_ptr()), "smoltts_mimi_reset")
+
+    def decode_chunk(self, codes: torch.Tensor, f0: int, n_frames: int, pcm: torch.Tensor, code_offset: int = 0) -> None:
+        """codes: device int32 [batch, F, row] (row >= code_offset + num_codebooks); decodes frames
+        [f0, f0+n_frames) of every slot into pcm[:, 1920*f0 : 1920*(f0+n_frames)]."""
+        batch, F, row = codes.shape
+        assert codes.dtype == torch.int32 and codes.is_contiguous() and pcm.dtype == torch.float32 and pcm.is_contiguous()
+        assert batch <= self.B and n_frames <= self.chunk and f0 + n_frames <= F
+        cptr = codes.data_ptr() + 4 * f0 * row
+        pptr = pcm.data_ptr() + 4 * f0 * self.SAMPLES_PER_FRAME
+        check(self.lib.smoltts_mimi_decode_chunk(self.handle, cptr, F * row, row, code_offset, batch, n_frames, pptr,
+                                                 pcm.shape[1], current_stream_ptr()), "smoltts_mimi_decode_chunk")
+
+    def decode(self, codes: torch.Tensor, code_offset: int = 0, reset: bool = True) -> torch.Tensor:
+        """codes device int32 [batch, F, row] -> pcm [batch, 1920 F] (== MimiModel.decode)."""
+        if reset:
+            self.reset()
+        batch, F, _ = codes.shape
+        pcm = torch.empty(batch, F * self.SAMPLES_PER_FRAME, dtype=torch.float32, device=codes.device)
+        for f0 in range(0, F, self.chunk):
+            self.decode_chunk(codes, f0, min(self.chunk, F - f0), pcm, code_offset)
+        return pcm
+
+    def close(self):
+        if getattr(self, "handle", None):
+            torch.cuda.synchronize()
+            self.lib.smoltts_mimi_session_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,95 @@
+"""Operator-level wrappers over the ``smoltts_k_*`` C entry points (device tensors in/out).
+
+These mirror the reference's building blocks one to one so the parity tests read like the
+reference modules: ``linear`` = RMSNorm/ELU + nn.Linear + epilogue (modeling/model/rq_transformer.py
+:535-613), ``attention`` = scaled_dot_product_attention over a KV cache, ``embed`` =
+BaseTransformer.embed, ``argmax`` = greedy sampling, ``layernorm`` = nn.LayerNorm.
+All of them run the HIP kernels; nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import engine as E
+from .packing import tile_t16x32
+
+
+def pack_weight(w: torch.Tensor, fp32: bool = False) -> torch.Tensor:
+    """Row-major [N, K] (CPU or GPU, any float dtype) -> T16x32 tiles on the current GPU."""
+    flat = tile_t16x32(w.detach().float().cpu(), torch.float32 if fp32 else torch.bfloat16)
+    return flat.cuda()
+
+
+def linear(x: torch.Tensor, w_tiles: torch.Tensor, N: int, *, w_fp32: bool = False, prologue: int = E.PRO_NONE,
+           epilogue: int = E.EPI_STORE, gamma: Optional[torch.Tensor] = None, eps: float = 1e-5,
+           bias: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
+           resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+           M: Optional[int] = None, K: Optional[int] = None, ldx: Optional[int] = None, x_bstride: int = 0,
+           rows_per_batch: int = 0, ldo: Optional[int] = None, o_bstride: int = 0, ldr: int = 0, r_bstride: int = 0,
+           rope: Optional[torch.Tensor] = None, row_pos: Optional[torch.Tensor] = None,
+           row_slot: Optional[torch.Tensor] = None, k_cache: Optional[torch.Tensor] = None,
+           v_cache: Optional[torch.Tensor] = None, n_q_heads: int = 0, n_kv_heads: int = 0, cache_len: int = 0) -> torch.Tensor:
+    lib = E.load_library()
+    M = x.shape[0] if M is None else M
+    K = x.shape[1] if K is None else K
+    out_cols = N // 2 if epilogue == E.EPI_SWIGLU else (n_q_heads * 64 if epilogue == E.EPI_QKV_ROPE else N)
+    if out is None:
+        out = torch.empty(M, out_cols, dtype=torch.float32, device=x.device)
+    a = E.GemmArgs()
+    a.w_dev, a.w_is_fp32, a.x_dev = E.dptr(w_tiles), int(w_fp32), E.dptr(x)
+    a.ldx = x.stride(0) if ldx is None else ldx
+    a.x_bstride, a.rows_per_batch, a.M, a.N, a.K = x_bstride, rows_per_batch, M, N, K
+    a.prologue, a.epilogue, a.gamma_dev, a.eps = prologue, epilogue, E.dptr(gamma), eps
+    a.bias_dev, a.scale_dev, a.resid_dev = E.dptr(bias), E.dptr(scale), E.dptr(resid)
+    a.ldr, a.r_bstride = ldr, r_bstride
+    a.out_dev = E.dptr(out)
+    a.ldo = (out.stride(0) if out.dim() == 2 else out_cols) if ldo is None else ldo
+    a.o_bstride = o_bstride
+    a.rope_dev, a.row_pos_dev, a.row_slot_dev = E.dptr(rope), E.dptr(row_pos), E.dptr(row_slot)
+    a.k_cache_dev, a.v_cache_dev = E.dptr(k_cache), E.dptr(v_cache)
+    a.n_q_heads, a.n_kv_heads, a.cache_len = n_q_heads, n_kv_heads, cache_len
+    E.check(lib.smoltts_k_gemm(C.byref(a), E.current_stream_ptr()), "smoltts_k_gemm")
+    return out
+
+
+def attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, row_pos: torch.Tensor,
+              row_slot: torch.Tensor, n_q_heads: int, window: int = 0) -> torch.Tensor:
+    """q [rows, Hq*64]; caches [slots, KV, cache_len, 64]; -> [rows, Hq*64]."""
+    lib = E.load_library()
+    n_kv, cache_len = k_cache.shape[1], k_cache.shape[2]
+    out = torch.empty_like(q)
+    E.check(lib.smoltts_k_attention(E.dptr(q), E.dptr(k_cache), E.dptr(v_cache), E.dptr(row_pos), E.dptr(row_slot),
+                                    q.shape[0], n_q_heads, n_kv, cache_len, window, E.dptr(out), E.current_stream_ptr()),
+            "smoltts_k_attention")
+    return out
+
+
+def embed(cols: torch.Tensor, text_emb: torch.Tensor, cb_emb: torch.Tensor, codebook_size: int, cb_first_offset: int = 0,
+          mask_mode: int = 0, sem_start: int = 320, sem_end: int = 2367) -> torch.Tensor:
+    """cols int32 [rows, 1+n]; bf16 tables; -> fp32 [rows, dim]."""
+    lib = E.load_library()
+    rows, dim = cols.shape[0], text_emb.shape[1]
+    x = torch.empty(rows, dim, dtype=torch.float32, device=cols.device)
+    E.check(lib.smoltts_k_embed(E.dptr(cols), rows, cols.shape[1] - 1, E.dptr(text_emb), E.dptr(cb_emb), dim, codebook_size,
+                                cb_first_offset, mask_mode, sem_start, sem_end, E.dptr(x), E.current_stream_ptr()),
+            "smoltts_k_embed")
+    return x
+
+
+def argmax(logits: torch.Tensor, margin: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = E.load_library()
+    ids = torch.empty(logits.shape[0], dtype=torch.int32, device=logits.device)
+    E.check(lib.smoltts_k_argmax(E.dptr(logits), logits.shape[0], logits.shape[1], logits.stride(0), E.dptr(ids), 1,
+                                 E.dptr(margin), E.current_stream_ptr()), "smoltts_k_argmax")
+    return ids
+
+
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    lib = E.load_library()
+    out = torch.empty_like(x)
+    E.check(lib.smoltts_k_layernorm(E.dptr(x), E.dptr(w), E.dptr(b), x.shape[0], x.shape[1], eps, E.dptr(out),
+                                    E.current_stream_ptr()), "smoltts_k_layernorm")
+    return out

@@ -1,0 +1,242 @@
+"""Host-side weight packing: reference checkpoints -> the device arena the HIP kernels stream.
+
+* ``tile_t16x32``      the MFMA-fragment tile order documented in include/smoltts_hip.h.
+* ``pack_lm``          torch / MLX state dicts of the DualAR model (keys of
+                       modeling/model/rq_transformer.py; fused ``wqkv`` or legacy ``wq/wk/wv``
+                       (load_hook :528-533); ``fast_output.weight`` as (n, d, 2048) torch layout or
+                       (n*2048, d) flattened MLX layout, train/convert_safetensors.py:10-15;
+                       ``_orig_mod.`` prefixes stripped, train/state.py) -> bf16 arena + offsets.
+* ``pack_mimi``        Hugging Face ``kyutai/mimi`` decoder-side keys (codec/mimi.py:107-156) ->
+                       fp32 arena + offsets, convolutions rewritten as GEMMs.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Tuple
+
+import torch
+
+from .config import NumericsMode, RQTransformerModelArgs
+
+ALIGN = 256
+
+
+def tile_t16x32(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Row-major [N][K] -> flat tiles; N zero-padded to 16, K must be a multiple of 32."""
+    assert w.dim() == 2
+    N, K = w.shape
+    if K % 32:
+        raise ValueError(f"K={K} must be a multiple of 32")
+    Np = (N + 15) // 16 * 16
+    if Np != N:
+        w = torch.cat([w, torch.zeros(Np - N, K, dtype=w.dtype)], dim=0)
+    w = w.to(dtype)
+    if dtype == torch.bfloat16:
+        t = w.reshape(Np // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4)  # nt, kc, q, r, 8
+    elif dtype == torch.float32:
+        t = w.reshape(Np // 16, 16, K // 32, 4, 2, 4).permute(0, 2, 4, 3, 1, 5)  # nt, kc, h, q, r, 4
+    else:
+        raise ValueError(dtype)
+    return t.contiguous().reshape(-1)
+
+
+def untile_t16x32(flat: torch.Tensor, N: int, K: int) -> torch.Tensor:
+    """Inverse of ``tile_t16x32`` (tests)."""
+    Np = (N + 15) // 16 * 16
+    if flat.dtype == torch.bfloat16:
+        t = flat.reshape(Np // 16, K // 32, 4, 16, 8).permute(0, 3, 1, 2, 4)
+    else:
+        t = flat.reshape(Np // 16, K // 32, 2, 4, 16, 4).permute(0, 4, 1, 3, 2, 5)
+    return t.reshape(Np, K)[:N].contiguous()
+
+
+class ArenaBuilder:
+    def __init__(self):
+        self.chunks: List[torch.Tensor] = []
+        self.size = 0
+
+    def add(self, t: torch.Tensor) -> int:
+        raw = t.contiguous().reshape(-1).view(torch.uint8)
+        off = self.size
+        self.chunks.append(raw)
+        pad = (-raw.numel()) % ALIGN
+        if pad:
+            self.chunks.append(torch.zeros(pad, dtype=torch.uint8))
+        self.size += raw.numel() + pad
+        return off
+
+    def finish(self) -> torch.Tensor:
+        return torch.cat(self.chunks) if self.chunks else torch.zeros(0, dtype=torch.uint8)
+
+
+def rope_table(n_pos: int, head_dim: int, base: float, bf16: bool) -> torch.Tensor:
+    """(n_pos, head_dim/2, 2) fp32 [cos, sin]; restates precompute_freqs_cis
+    (modeling/model/rq_transformer.py:616-624) including its bf16 rounding when ``bf16``."""
+    freqs = 1.0 / (base ** (torch.arange(0, head_dim, 2)[: head_dim // 2].float() / head_dim))
+    ang = torch.outer(torch.arange(n_pos), freqs)
+    fc = torch.polar(torch.ones_like(ang), ang)
+    cache = torch.stack([fc.real, fc.imag], dim=-1)
+    if bf16:
+        cache = cache.to(torch.bfloat16)
+    return cache.float().contiguous()
+
+
+def _clean(state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    return {k.replace("_orig_mod.", ""): v for k, v in state.items()}
+
+
+def _wqkv(st, prefix):
+    if prefix + "attention.wqkv.weight" in st:
+        return st[prefix + "attention.wqkv.weight"]
+    return torch.cat([st[prefix + f"attention.{n}.weight"] for n in ("wq", "wk", "wv")])
+
+
+def pack_lm(cfg: RQTransformerModelArgs, state: Dict[str, torch.Tensor], numerics: NumericsMode):
+    """-> (arena uint8 CPU tensor, offsets dict). Matrices/embeddings are stored as bf16."""
+    st = _clean(state)
+    ab = ArenaBuilder()
+    bf = torch.bfloat16
+    off: Dict[str, object] = {}
+
+    def f32(k):
+        return st[k].float()
+
+    def block(prefix):
+        w1, w3 = st[prefix + "feed_forward.w1.weight"], st[prefix + "feed_forward.w3.weight"]
+        w13 = torch.stack([w1.float(), w3.float()], dim=1).reshape(2 * w1.shape[0], w1.shape[1])
+        return {
+            "attn_norm": ab.add(f32(prefix + "attention_norm.weight")),
+            "wqkv": ab.add(tile_t16x32(_wqkv(st, prefix).float(), bf)),
+            "wo": ab.add(tile_t16x32(f32(prefix + "attention.wo.weight"), bf)),
+            "ffn_norm": ab.add(f32(prefix + "ffn_norm.weight")),
+            "w13": ab.add(tile_t16x32(w13, bf)),
+            "w2": ab.add(tile_t16x32(f32(prefix + "feed_forward.w2.weight"), bf)),
+        }
+
+    emb = f32("embeddings.weight")
+    off["text_emb"] = ab.add(emb.to(bf))
+    off["codebook_emb"] = ab.add(f32("codebook_embeddings.weight").to(bf))
+    off["fast_emb"] = ab.add(f32("fast_embeddings.weight").to(bf))
+    off["norm"] = ab.add(f32("norm.weight"))
+    head = emb if cfg.tie_word_embeddings else f32("output.weight")
+    off["head"] = ab.add(tile_t16x32(head, bf))
+    off["fast_norm"] = ab.add(f32("fast_norm.weight"))
+    fo = f32("fast_output.weight")
+    n_fast, cs, fd = cfg.max_fast_seqlen, cfg.codebook_size, cfg.fast_dim
+    if cfg.depthwise_output:
+        if fo.dim() == 3:  # torch (n, d, cs): logits_i = h @ W[i]  => rows = W[i].T
+            fo = fo.permute(0, 2, 1).reshape(n_fast * cs, fd)
+        elif fo.shape != (n_fast * cs, fd):
+            raise ValueError(f"fast_output.weight has shape {tuple(fo.shape)}")
+        off["fast_head_step_stride"] = cs
+    else:
+        if fo.shape != (cs, fd):
+            raise ValueError(f"fast_output.weight has shape {tuple(fo.shape)}")
+        off["fast_head_step_stride"] = 0
+    off["fast_head"] = ab.add(tile_t16x32(fo, bf))
+    if cfg.fast_dim != cfg.dim:
+        off["fast_proj_w"] = ab.add(tile_t16x32(f32("fast_project_in.weight"), bf))
+        off["fast_proj_b"] = ab.add(f32("fast_project_in.bias"))
+    else:
+        off["fast_proj_w"] = off["fast_proj_b"] = 0
+    off["rope"] = ab.add(rope_table(cfg.max_seq_len, cfg.head_dim, cfg.rope_base, numerics.rope_bf16))
+    off["fast_rope"] = ab.add(rope_table(n_fast, cfg.fast_head_dim, cfg.rope_base, numerics.rope_bf16))
+    off["layers"] = [block(f"layers.{i}.") for i in range(cfg.n_layer)]
+    off["fast_layers"] = [block(f"fast_layers.{i}.") for i in range(cfg.n_fast_layer)]
+    return ab.finish(), off
+
+
+# ------------------------------------------------------------------------------------- Mimi
+RATIOS = (8, 6, 5, 4)
+_HALF_SPLIT_PERM = torch.tensor([j // 2 + 32 * (j % 2) for j in range(64)])  # new row 2j <- j, 2j+1 <- j+32
+
+
+def _perm_heads(w: torch.Tensor, n_heads: int = 8) -> torch.Tensor:
+    """Reorder the rows of a q/k projection so that the half-split RoPE pair (j, j+32) of every head
+    becomes the interleaved pair (2j, 2j+1).  q.k dot products are invariant under a common
+    permutation of head dims, so attention is unchanged (codec/transformer.py:63-67 uses
+    nn.RoPE(traditional=False))."""
+    d = w.shape[0] // n_heads
+    idx = torch.cat([h * d + _HALF_SPLIT_PERM for h in range(n_heads)])
+    return w[idx]
+
+
+def conv_as_gemm(w: torch.Tensor, b: torch.Tensor, transposed: bool, stride: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """GEMM form [N][K] of a causal conv over channel-last rows (DESIGN.md 'convolutions as GEMMs').
+
+    Conv1d (cout, cin, k), stride 1: row t of the output reads the k consecutive input rows ending
+    at t: W'[co][j*cin + ci] = w[co][ci][j].
+    ConvTranspose1d (cin, cout, k = 2*stride): output rows t*s + r, r < s, read input rows (t-1, t):
+    W'[r*cout + co][ci] = w[ci][co][r + s] and W'[r*cout + co][cin + ci] = w[ci][co][r]."""
+    if not transposed:
+        cout, cin, k = w.shape
+        return w.permute(0, 2, 1).reshape(cout, k * cin).contiguous(), b.clone()
+    cin, cout, k = w.shape
+    s = stride
+    assert k == 2 * s
+    prev = w[:, :, s:].permute(2, 1, 0)  # r, co, ci   (input row t-1)
+    cur = w[:, :, :s].permute(2, 1, 0)   # r, co, ci   (input row t)
+    return torch.cat([prev, cur], dim=2).reshape(s * cout, 2 * cin).contiguous(), b.repeat(s)
+
+
+def mimi_conv_specs():
+    """(hf key, cin, cout, k, stride, transposed) in execution order (codec/seanet.py:99-139)."""
+    specs = [("0", 512, 1024, 7, 1, False)]
+    ch, li = 1024, 1
+    for r in RATIOS:
+        specs.append((str(li + 1), ch, ch // 2, 2 * r, r, True))
+        specs.append((f"{li + 2}.block.1", ch // 2, ch // 4, 3, 1, False))
+        specs.append((f"{li + 2}.block.3", ch // 4, ch // 2, 1, 1, False))
+        ch //= 2
+        li += 3
+    specs.append(("14", 64, 1, 3, 1, False))
+    return specs
+
+
+def pack_mimi(state: Dict[str, torch.Tensor], num_codebooks: int = 8, max_positions: int = 4096):
+    st = {k: v.float() for k, v in state.items()}
+    ab = ArenaBuilder()
+    f32 = torch.float32
+    off: Dict[str, object] = {}
+    # RVQ: fold embed = embed_sum / max(usage, eps) (rvq.py:41-48) and the group's 1x1 output_proj
+    tables = []
+    for q in range(num_codebooks):
+        grp = "semantic" if q == 0 else "acoustic"
+        p = f"quantizer.{grp}_residual_vector_quantizer."
+        li = 0 if q == 0 else q - 1
+        emb = st[p + f"layers.{li}.codebook.embed_sum"] / torch.clamp(st[p + f"layers.{li}.codebook.cluster_usage"], min=1e-5)[:, None]
+        proj = st[p + "output_proj.weight"][:, :, 0]  # (512, 256)
+        tables.append((emb.double() @ proj.double().T).float())
+    off["rvq_table"] = ab.add(torch.stack(tables))
+    off["upsample_w"] = ab.add(st["upsample.conv.weight"][:, 0, :].T.contiguous())  # [4][512]
+    off["rope"] = ab.add(rope_table(max_positions, 64, 10000.0, bf16=False))
+    n_layers = 1 + max(int(k.split(".")[2]) for k in st if k.startswith("decoder_transformer.layers."))
+    layers = []
+    for li in range(n_layers):
+        p = f"decoder_transformer.layers.{li}."
+        wq, wk, wv = (st[p + f"self_attn.{n}_proj.weight"] for n in ("q", "k", "v"))
+        wqkv = torch.cat([_perm_heads(wq), _perm_heads(wk), wv])
+        layers.append({
+            "ln1_w": ab.add(st[p + "input_layernorm.weight"]), "ln1_b": ab.add(st[p + "input_layernorm.bias"]),
+            "wqkv": ab.add(tile_t16x32(wqkv, f32)),
+            "wo": ab.add(tile_t16x32(st[p + "self_attn.o_proj.weight"], f32)),
+            "ls1": ab.add(st[p + "self_attn_layer_scale.scale"]),
+            "ln2_w": ab.add(st[p + "post_attention_layernorm.weight"]), "ln2_b": ab.add(st[p + "post_attention_layernorm.bias"]),
+            "fc1": ab.add(tile_t16x32(st[p + "mlp.fc1.weight"], f32)),
+            "fc2": ab.add(tile_t16x32(st[p + "mlp.fc2.weight"], f32)),
+            "ls2": ab.add(st[p + "mlp_layer_scale.scale"]),
+        })
+    off["layers"] = layers
+    convs = []
+    for key, cin, cout, k, stride, tr in mimi_conv_specs():
+        w, b = st[f"decoder.layers.{key}.conv.weight"], st[f"decoder.layers.{key}.conv.bias"]
+        expect = (cin, cout, k) if tr else (cout, cin, k)
+        if tuple(w.shape) != expect:
+            raise ValueError(f"decoder.layers.{key}.conv.weight has shape {tuple(w.shape)}, expected {expect}")
+        gw, gb = conv_as_gemm(w, b, tr, stride)
+        convs.append({"w": ab.add(tile_t16x32(gw, f32)), "b": ab.add(gb), "cin": cin, "cout": cout, "k": k,
+                      "stride": stride, "transposed": int(tr)})
+    off["convs"] = convs
+    off["n_layers"] = n_layers
+    off["max_positions"] = max_positions
+    return ab.finish(), off

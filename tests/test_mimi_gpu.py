@@ -1,0 +1,89 @@
+"""Mimi decode parity: HIP engine (through the C ABI) vs the CPU oracle on seeded random weights.
+Tolerance: RMS(pcm_hip - pcm_oracle) <= 1e-4 (BASELINE.json north_star), on a signal of RMS ~0.2;
+in practice the fp32 pipeline lands near 1e-6."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RMS_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def mimi():
+    from oracle.mimi_oracle import MimiDecodeOracle
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+    from smoltts_amd.engine import MimiEngine
+
+    st = synthetic_mimi_state(seed=3)
+    return st, MimiEngine(st, num_codebooks=8, window=0, max_positions=256), MimiDecodeOracle(st, window=0)
+
+
+def _rms(a):
+    return float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
+
+
+@pytest.mark.parametrize("B,F,chunk", [(1, 1, 1), (1, 5, 5), (3, 7, 2), (2, 9, 4), (2, 6, 1)])
+def test_decode_matches_oracle(mimi, B, F, chunk):
+    from smoltts_amd.engine import MimiSession
+
+    st, eng, orc = mimi
+    g = torch.Generator().manual_seed(B * 100 + F)
+    codes = torch.randint(0, 2048, (B, 8, F), generator=g)
+    ref = orc.decode(codes)[:, 0].numpy()  # B, 1920 F
+    sess = MimiSession(eng, max_batch=B, max_chunk_frames=chunk)
+    dev_codes = codes.permute(0, 2, 1).contiguous().int().cuda()  # [B, F, 8]
+    pcm = sess.decode(dev_codes).cpu().numpy()
+    assert pcm.shape == ref.shape
+    err = _rms(pcm - ref)
+    print(f"B={B} F={F} chunk={chunk}: rms err {err:.3e}, signal rms {_rms(ref):.3f}, max err {np.abs(pcm - ref).max():.3e}")
+    assert err <= RMS_TOL
+    # second utterance set on the same session after reset: state must not leak
+    pcm2 = sess.decode(dev_codes).cpu().numpy()
+    assert np.array_equal(pcm, pcm2)
+    sess.close()
+
+
+def test_codes_embedded_in_lm_rows(mimi):
+    """The LM session stores columns as [slow id, c0..c7]; Mimi reads them in place (code_offset=1)."""
+    from smoltts_amd.engine import MimiSession
+
+    st, eng, orc = mimi
+    g = torch.Generator().manual_seed(8)
+    B, F = 2, 4
+    cols = torch.randint(0, 2048, (B, F + 3, 9), generator=g).int()
+    ref = orc.decode(cols[:, :F, 1:].permute(0, 2, 1).long())[:, 0].numpy()
+    sess = MimiSession(eng, max_batch=B, max_chunk_frames=4)
+    sess.reset()
+    pcm = torch.empty(B, F * 1920, device="cuda")
+    sess.decode_chunk(cols.cuda(), 0, F, pcm, code_offset=1)
+    assert _rms(pcm.cpu().numpy() - ref) <= RMS_TOL
+    sess.close()
+
+
+def test_window_matches_hf_semantics():
+    """window=W restricts attention to the last W positions (transformers.MimiModel sliding_window)."""
+    from oracle.mimi_oracle import MimiDecodeOracle
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+    from smoltts_amd.engine import MimiEngine, MimiSession
+
+    st = synthetic_mimi_state(seed=4)
+    eng = MimiEngine(st, window=6, max_positions=64)
+    orc = MimiDecodeOracle(st, window=6)
+    codes = torch.randint(0, 2048, (1, 8, 10), generator=torch.Generator().manual_seed(1))
+    sess = MimiSession(eng, max_batch=1, max_chunk_frames=3)
+    pcm = sess.decode(codes.permute(0, 2, 1).contiguous().int().cuda()).cpu().numpy()
+    assert _rms(pcm - orc.decode(codes)[:, 0].numpy()) <= RMS_TOL
+    sess.close()
+
+
+def test_capacity_error(mimi):
+    from smoltts_amd.engine import MimiSession, SmolttsError
+
+    st, eng, orc = mimi
+    sess = MimiSession(eng, max_batch=1, max_chunk_frames=64)
+    codes = torch.zeros(1, 200, 8, dtype=torch.int32).cuda()
+    with pytest.raises(SmolttsError):
+        sess.decode(codes)  # 400 positions > max_positions=256
+    sess.close()
