@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Throughput bench of the hot path: greedy DualAR decode + Mimi decode to PCM.
+
+Metric (BASELINE.json): Mimi frames/s (= 12.5 x real-time factor), whole job over all GPUs.
+Workload at N=1 (BASELINE.json configs[2]): smoltts_byte_150m, bf16 weights, B=32 concurrent
+utterances, synthetic ChatML prompts, seeded random weights, greedy, EOS disabled.
+
+One *step* = one chunk of CH frames for all B slots of the rank: CH replays of the captured
+frame graph (slow step + 8 depth steps + on-device argmax each) followed by one Mimi chunk decode
+of those CH x B frames to PCM, everything resident in HBM.  Prompt prefill happens before the
+timed region (the reference's own "x realtime" excludes it, lm/generate.py:199-214) and is
+reported separately.  N > 1: one process per GPU, utterances sharded by rank (weak scaling, no
+per-step collective), weights broadcast from rank 0 over RCCL.
+
+Output: ONE JSON line on rank 0 (driver contract) with `roofline` (dominant kernel: the fused
+RMSNorm + w1|w3 GEMM + SwiGLU, timed in situ with HIP events) and `cpu_baseline` (the CPU oracle,
+fp32 torch eager, timed on this host on a bounded sample).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("TORCH_COMPILE_DISABLE", "1")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def make_prompts(pe, n_total, seed=2):
+    """voice u mod 11, printable-ASCII text of length U{40..160}."""
+    from smoltts_amd.prompt import VOICES
+
+    rng = np.random.default_rng(seed)
+    out = []
+    for u in range(n_total):
+        n = int(rng.integers(40, 161))
+        text = "".join(chr(int(c)) for c in rng.integers(32, 127, size=n))
+        out.append(pe.build_prompt(text, VOICES[u % len(VOICES)]))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--model", default="smoltts_byte_150m")
+    ap.add_argument("--batch", type=int, default=32, help="utterance slots per GPU")
+    ap.add_argument("--chunk", type=int, default=8, help="frames per step")
+    ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    from smoltts_amd import parallel
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+    from smoltts_amd.config import NumericsMode, TokenConfig
+    from smoltts_amd.engine import (EPI_SWIGLU, PRO_RMSNORM, LMEngine, LMSession, MimiEngine, MimiSession, check,
+                                    load_library)
+    from smoltts_amd.packing import pack_lm, pack_mimi
+    from smoltts_amd.prompt import PromptEncoder
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+    from smoltts_amd.tokenizer import load_tokenizer
+
+    rank, world, local = parallel.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    lib = load_library()
+
+    B, CH, K, W = args.batch, args.chunk, args.steps, args.warmup
+    cfg = named_config(args.model)
+    tok = load_tokenizer()
+    tc = TokenConfig.from_tokenizer(tok, cfg)
+    numerics = NumericsMode.torch_reference()
+    total_frames = 1 + (W + K) * CH + 4  # frame 0 from prefill, +4 for the in-situ kernel timing frames
+
+    # ---- weights: rank 0 builds + packs, everyone receives them over RCCL
+    state = mstate = None
+    arena = offsets = m_arena = m_offsets = None
+    if rank == 0:
+        state = synthetic_lm_state(cfg, seed=0)
+        arena, offsets = pack_lm(cfg, state, numerics)
+        mstate = synthetic_mimi_state(seed=0)
+        m_arena, m_offsets = pack_mimi(mstate, 8, max_positions=2 * total_frames + 16)
+    arena, offsets = parallel.broadcast_weights(arena, offsets, dev)
+    m_arena, m_offsets = parallel.broadcast_weights(m_arena, m_offsets, dev)
+    eng = LMEngine(cfg, None, tc, numerics, arena=arena, offsets=offsets)
+    meng = MimiEngine(None, 8, window=0, arena=m_arena, offsets=m_offsets)
+
+    # ---- inputs: utterance u -> rank u mod world
+    pe = PromptEncoder(tok, tc.semantic_start_id, cfg.num_codebooks, cfg.duplicate_code_0)
+    all_prompts = make_prompts(pe, B * world)
+    mine = [all_prompts[u] for u in parallel.shard_utterances(B * world, rank, world)]
+    max_T = max(p.shape[1] for p in mine)
+    sess = LMSession(eng, max_batch=B, max_seq=max_T + total_frames + 8, max_rows=sum(p.shape[1] for p in mine),
+                     max_frames=total_frames)
+    msess = MimiSession(meng, max_batch=B, max_chunk_frames=CH)
+    pcm = torch.zeros(B, total_frames * 1920, dtype=torch.float32, device=dev)
+
+    def step(i):
+        sess.decode(CH)
+        msess.decode_chunk(sess.codes, i * CH, CH, pcm, code_offset=1)
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sess.prefill(mine, stop_on_eos=False)
+    torch.cuda.synchronize()
+    prefill_ms = (time.perf_counter() - t0) * 1e3
+    msess.reset()
+    for i in range(W):
+        step(i)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        step(i)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    elapsed = parallel.all_reduce_max(time.perf_counter() - t0, dev)
+    frames_done = parallel.all_reduce_sum(float(B * CH * K), dev)
+    value = frames_done / elapsed
+
+    codes, n_frames, done, margin = sess.fetch()
+    assert int(n_frames.min()) == 1 + (W + K) * CH, (n_frames, 1 + (W + K) * CH)
+    assert bool(torch.isfinite(pcm[:, : (W + K) * CH * 1920]).all())
+
+    # ---- dominant kernel in situ: eager frames with HIP events around every w1|w3 GEMM launch
+    roofline = None
+    if rank == 0 and not args.no_kernel_timing:
+        os.environ["SMOLTTS_NO_GRAPH"] = "1"
+        n_launch_per_frame = cfg.n_layer + cfg.n_fast_layer * cfg.max_fast_seqlen
+        sess.decode(1)  # eager warm-up frame
+        check(lib.smoltts_profile_begin(PRO_RMSNORM, EPI_SWIGLU, 2 * cfg.intermediate_size, 4 * n_launch_per_frame), "profile_begin")
+        sess.decode(3)
+        tot, cnt = ctypes.c_float(), ctypes.c_int32()
+        check(lib.smoltts_profile_end(ctypes.byref(tot), ctypes.byref(cnt)), "profile_end")
+        os.environ["SMOLTTS_NO_GRAPH"] = "0"
+        avg_us = tot.value * 1e3 / max(cnt.value, 1)
+        # algorithmic bytes of one launch: bf16 w1|w3 tiles + fp32 x in + fp32 h out + norm weight
+        bytes_alg = 2 * cfg.intermediate_size * cfg.dim * 2 + B * cfg.dim * 4 + B * cfg.intermediate_size * 4 + cfg.dim * 4
+        ach = bytes_alg / (avg_us * 1e-6) / 1e9
+        roofline = {"bound": "hbm", "kernel": "gemm_kernel<bf16,MT=2,RMSNorm,SwiGLU> (w1|w3)", "achieved": round(ach, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_us": round(avg_us, 3), "launches_timed": cnt.value, "bytes_per_launch": bytes_alg}
+
+    # ---- CPU baseline: the oracle (fp32 torch eager) on the same weights/prompts, bounded sample
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        from oracle.lm_oracle import LMOracle, OracleLMConfig
+        from oracle.mimi_oracle import MimiDecodeOracle
+
+        torch.set_num_threads(os.cpu_count() or 1)
+        nF = args.cpu_frames
+        orc = LMOracle(OracleLMConfig.from_dict(cfg.__dict__), state, embed_mask=numerics.embed_mask, rope_bf16=numerics.rope_bf16)
+        with torch.no_grad():
+            orc._alloc(B, max_T + nF + 2)
+            hidden = torch.stack([orc.prefill_one(b, torch.from_numpy(mine[b]).long()) for b in range(B)])
+            cols_all = []
+            t_lm = 0.0
+            for f in range(nF + 1):  # frame 0 is the warm-up, untimed
+                t1 = time.perf_counter()
+                ids = orc.slow_head(hidden).argmax(-1)
+                cds, _ = orc.fast_decode(hidden)
+                cols = torch.cat([ids[:, None], cds], dim=1)
+                hidden = orc.decode_cols(cols)
+                if f > 0:
+                    t_lm += time.perf_counter() - t1
+                cols_all.append(cols)
+            grid = torch.stack(cols_all, dim=1)  # B, nF+1, 9
+            morc = MimiDecodeOracle(mstate)
+            t1 = time.perf_counter()
+            ref_pcm = morc.decode(grid[:, 1:, 1:].permute(0, 2, 1).contiguous())
+            t_mimi = time.perf_counter() - t1
+        cpu = {"value": round(B * nF / (t_lm + t_mimi), 2), "unit": "frames/s", "cores": torch.get_num_threads(),
+               "kind": "port", "sample": f"{nF} decode frames x {B} utterances (150m oracle, fp32 torch eager, KV-cached) "
+               f"+ Mimi decode of those frames; LM {t_lm:.2f}s, Mimi {t_mimi:.2f}s; prefill and 1 warm-up frame untimed"}
+        same = np.array_equal(codes[:, : nF + 1], grid.numpy())
+        pcm_ref_full = MimiDecodeOracle(mstate).decode(grid[:, :, 1:].permute(0, 2, 1).contiguous())[:, 0].numpy()
+        rms = float(np.sqrt(np.mean((pcm[:, : (nF + 1) * 1920].cpu().numpy() - pcm_ref_full) ** 2)))
+        parity = {"frames_checked": nF + 1, "ids_bit_identical": bool(same), "pcm_rms_err": rms}
+
+    if rank == 0:
+        out = {
+            "metric": "Mimi frames/sec (=12.5 x RTF), greedy DualAR decode + Mimi decode to PCM",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16 weights, fp32 activations/accumulate (LM); fp32 (Mimi)",
+            "data": "synthetic (seeded random weights at the real shapes, synthetic ChatML prompts)",
+            "config": {"workload": f"{args.model} B={B}/GPU concurrent utterances, chunk {CH} frames/step, "
+                                   f"prompts T={min(p.shape[1] for p in mine)}..{max_T}, context {max_T + W * CH}..{max_T + (W + K) * CH}",
+                       "global_batch": B * world, "frames_per_step": B * CH * world, "parallelism": f"dp{world} (utterance-sharded replicas)"},
+            "rtf": round(value / 12.5, 1), "frames_per_s_per_gpu": round(value / world, 1),
+            "us_per_frame_step": round(elapsed / (K * CH) * 1e6, 1), "prefill_ms": round(prefill_ms, 2),
+            "min_top2_margin": float(margin.min()),
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+        }
+        print(json.dumps(out), flush=True)
+    msess.close()
+    sess.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

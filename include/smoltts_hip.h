@@ -253,6 +253,13 @@ typedef struct SmolttsGemmArgs {
 
 int smoltts_k_gemm(const SmolttsGemmArgs* a, void* stream);
 
+/* Measurement hook (bench.py): between begin and end, every GEMM launch whose prologue/epilogue
+ * (and N, when n_filter > 0) match is bracketed by a pair of hipEvents on the stream it is launched
+ * on.  Use with eager launches only (SMOLTTS_NO_GRAPH=1); events cannot be recorded into a graph
+ * being captured.  profile_end synchronises the events and returns the summed kernel time. */
+int smoltts_profile_begin(int32_t prologue, int32_t epilogue, int32_t n_filter, int32_t max_launches);
+int smoltts_profile_end(float* total_ms, int32_t* n_launches);
+
 /* GQA attention of one query row per (row, kv head) over the slot's cache prefix:
  * keys [max(0, pos+1-window), pos]; q_dev/out_dev [n_rows][n_q_heads*64]. */
 int smoltts_k_attention(const float* q_dev, const float* k_cache_dev, const float* v_cache_dev,

@@ -85,7 +85,7 @@ _EXPORTS = [
     "smoltts_lm_decode", "smoltts_session_outputs", "smoltts_mimi_create", "smoltts_mimi_destroy",
     "smoltts_mimi_slab_bytes", "smoltts_mimi_session_create", "smoltts_mimi_session_destroy", "smoltts_mimi_reset",
     "smoltts_mimi_decode_chunk", "smoltts_k_gemm", "smoltts_k_attention", "smoltts_k_embed", "smoltts_k_argmax",
-    "smoltts_k_layernorm",
+    "smoltts_k_layernorm", "smoltts_profile_begin", "smoltts_profile_end",
 ]
 
 
@@ -131,6 +131,8 @@ def load_library(path: Optional[Path] = None):
     lib.smoltts_k_embed.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]
     lib.smoltts_k_argmax.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.smoltts_k_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
+    lib.smoltts_profile_begin.argtypes = [C.c_int32] * 4
+    lib.smoltts_profile_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     if lib.smoltts_abi_version() != 1:
         raise SmolttsError("libsmoltts_hip.so ABI version mismatch")
     if path is None:
@@ -327,10 +329,14 @@ class LMSession:
 
 # ------------------------------------------------------------------------------- Mimi engine
 class MimiEngine:
-    def __init__(self, state: Dict[str, torch.Tensor], num_codebooks: int = 8, window: int = 0, max_positions: int = 4096):
+    def __init__(self, state: Optional[Dict[str, torch.Tensor]], num_codebooks: int = 8, window: int = 0,
+                 max_positions: int = 4096, arena: Optional[torch.Tensor] = None, offsets=None):
         self.lib = load_library()
         self.device = _require_gpu()
-        arena, off = packing.pack_mimi(state, num_codebooks, max_positions)
+        if arena is None:
+            arena, offsets = packing.pack_mimi(state, num_codebooks, max_positions)
+        off = offsets
+        max_positions = off["max_positions"]
         self.arena = arena.to(self.device)
         self.num_codebooks = num_codebooks
         cfg = MimiConfig(num_codebooks, off["n_layers"], window, max_positions)

@@ -1,0 +1,73 @@
+"""Multi-GPU data parallelism for independent utterances.
+
+Utterances share no state (the reference's generator is per request, lm/generate.py:25-57), so
+the path shards by utterance: one process per GPU, every rank holds a full replica and its own
+slots; there is no per-step exchange.  The only collectives are a start-up broadcast of the packed
+weight arena from rank 0 (RCCL over xGMI on GPUs, gloo in the CPU tests) and small reductions of
+counters / timings for reporting.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def dist_env() -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from the torch.distributed.run environment (1 process => 0,1,0)."""
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+
+
+def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    rank, world, local = dist_env()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_utterances(n: int, rank: int, world: int) -> List[int]:
+    """Round-robin utterance -> rank map ``u mod world``."""
+    return list(range(rank, n, world))
+
+
+def broadcast_weights(arena: Optional[torch.Tensor], offsets, device, src: int = 0):
+    """Rank ``src`` passes its packed arena (any device) and offsets; every rank returns
+    (arena on ``device``, offsets).  One message for the metadata, one for the bytes."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return arena.to(device), offsets
+    rank = dist.get_rank()
+    meta = [offsets, int(arena.numel())] if rank == src else [None, None]
+    dist.broadcast_object_list(meta, src=src)
+    offsets, nbytes = meta
+    buf = arena.to(device) if rank == src else torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dist.broadcast(buf, src=src)
+    return buf, offsets
+
+
+def all_reduce_max(value: float, device) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def all_reduce_sum(value: float, device) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def barrier() -> None:
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
