@@ -34,6 +34,24 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """Progress on stderr (the JSON line on stdout stays alone)."""
+    if int(os.environ.get("RANK", 0)) == 0:
+        print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads():
+    """CPU threads this process may really use (cgroup/affinity aware, capped at the 1-GPU share of 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def make_prompts(pe, n_total, seed=2):
     """voice u mod 11, printable-ASCII text of length U{40..160}."""
     from smoltts_amd.prompt import VOICES
@@ -69,6 +87,7 @@ def main():
     from smoltts_amd.synthetic import named_config, synthetic_lm_state
     from smoltts_amd.tokenizer import load_tokenizer
 
+    torch.set_num_threads(host_threads())
     rank, world, local = parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -87,10 +106,12 @@ def main():
     state = mstate = None
     arena = offsets = m_arena = m_offsets = None
     if rank == 0:
+        log(f"building synthetic {args.model} + Mimi weights ({torch.get_num_threads()} host threads)")
         state = synthetic_lm_state(cfg, seed=0)
         arena, offsets = pack_lm(cfg, state, numerics)
         mstate = synthetic_mimi_state(seed=0)
         m_arena, m_offsets = pack_mimi(mstate, 8, max_positions=2 * total_frames + 16)
+        log(f"packed: LM arena {arena.numel() / 1e6:.1f} MB, Mimi arena {m_arena.numel() / 1e6:.1f} MB")
     arena, offsets = parallel.broadcast_weights(arena, offsets, dev)
     m_arena, m_offsets = parallel.broadcast_weights(m_arena, m_offsets, dev)
     eng = LMEngine(cfg, None, tc, numerics, arena=arena, offsets=offsets)
@@ -110,6 +131,7 @@ def main():
         sess.decode(CH)
         msess.decode_chunk(sess.codes, i * CH, CH, pcm, code_offset=1)
 
+    log(f"sessions ready (B={B}, max_seq={sess.max_seq}); prefill of {sum(p.shape[1] for p in mine)} prompt rows")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     sess.prefill(mine, stop_on_eos=False)
@@ -130,6 +152,7 @@ def main():
     elapsed = parallel.all_reduce_max(time.perf_counter() - t0, dev)
     frames_done = parallel.all_reduce_sum(float(B * CH * K), dev)
     value = frames_done / elapsed
+    log(f"timed {K} steps: {elapsed * 1e3:.1f} ms -> {value:.0f} frames/s")
 
     codes, n_frames, done, margin = sess.fetch()
     assert int(n_frames.min()) == 1 + (W + K) * CH, (n_frames, 1 + (W + K) * CH)
@@ -147,6 +170,7 @@ def main():
         check(lib.smoltts_profile_end(ctypes.byref(tot), ctypes.byref(cnt)), "profile_end")
         os.environ["SMOLTTS_NO_GRAPH"] = "0"
         avg_us = tot.value * 1e3 / max(cnt.value, 1)
+        log(f"in-situ w1|w3 GEMM: {cnt.value} launches, avg {avg_us:.2f} us")
         # algorithmic bytes of one launch: bf16 w1|w3 tiles + fp32 x in + fp32 h out + norm weight
         bytes_alg = 2 * cfg.intermediate_size * cfg.dim * 2 + B * cfg.dim * 4 + B * cfg.intermediate_size * 4 + cfg.dim * 4
         ach = bytes_alg / (avg_us * 1e-6) / 1e9
@@ -161,8 +185,8 @@ def main():
         from oracle.lm_oracle import LMOracle, OracleLMConfig
         from oracle.mimi_oracle import MimiDecodeOracle
 
-        torch.set_num_threads(os.cpu_count() or 1)
         nF = args.cpu_frames
+        log(f"CPU oracle sample: prefill {B} prompts + {nF + 1} frames on {torch.get_num_threads()} threads")
         orc = LMOracle(OracleLMConfig.from_dict(cfg.__dict__), state, embed_mask=numerics.embed_mask, rope_bf16=numerics.rope_bf16)
         with torch.no_grad():
             orc._alloc(B, max_T + nF + 2)
@@ -178,11 +202,13 @@ def main():
                 if f > 0:
                     t_lm += time.perf_counter() - t1
                 cols_all.append(cols)
+                log(f"  oracle frame {f} done")
             grid = torch.stack(cols_all, dim=1)  # B, nF+1, 9
             morc = MimiDecodeOracle(mstate)
             t1 = time.perf_counter()
             ref_pcm = morc.decode(grid[:, 1:, 1:].permute(0, 2, 1).contiguous())
             t_mimi = time.perf_counter() - t1
+            log(f"  oracle Mimi decode done ({t_mimi:.1f}s)")
         cpu = {"value": round(B * nF / (t_lm + t_mimi), 2), "unit": "frames/s", "cores": torch.get_num_threads(),
                "kind": "port", "sample": f"{nF} decode frames x {B} utterances (150m oracle, fp32 torch eager, KV-cached) "
                f"+ Mimi decode of those frames; LM {t_lm:.2f}s, Mimi {t_mimi:.2f}s; prefill and 1 warm-up frame untimed"}

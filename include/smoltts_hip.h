@@ -253,6 +253,42 @@ typedef struct SmolttsGemmArgs {
 
 int smoltts_k_gemm(const SmolttsGemmArgs* a, void* stream);
 
+/* bf16-MFMA GEMM of the DualAR transformer (smoltts_amd/csrc/gemm3.hip).  The activation operand is
+ * in the "X3" format (smoltts_amd/csrc/x3.h): rows in tiles of 16, K in chunks of 32, block
+ * (row tile, chunk, piece p in 0..2) = 1 KiB at ((tile * K/32 + chunk) * 3 + p) * 1024 holding for
+ * lane l = 16*q + r the 8 bf16 of piece p of x[16*tile + r][32*chunk + 8q .. +8); the three pieces
+ * sum exactly to the fp32 value (already multiplied by the consumer's RMSNorm weight).  Buffer
+ * size: ceil(M/16)*16 * K * 6 bytes. */
+typedef struct SmolttsGemm3Args {
+  const void* w_dev;           /* bf16 T16x32 [N][K] */
+  const void* x3_dev;          /* X3 operand [M][K] */
+  int32_t M, N, K;
+  int32_t epilogue;            /* SMOLTTS_EPI_STORE | _RESID | _SWIGLU | _QKV_ROPE */
+  const float* ssq_in_dev;     /* [M][K/16] partial sums of squares of the un-normed input rows: the result
+                                  rows are scaled by rsqrt(sum/K + eps); NULL = input not normed */
+  float eps;
+  const float* bias_dev;       /* [N] or NULL */
+  const float* resid_dev;      /* EPI_RESID: fp32 [M][ldo] */
+  float* out_dev;              /* fp32 [M][ldo]: STORE / RESID result, QKV_ROPE q rows */
+  int64_t ldo;
+  void* x3_out_dev;            /* EPI_SWIGLU: X3 [M][N/2] of silu(gate) * up */
+  /* STORE / RESID: also publish the result for the next GEMM(s): X3 of out * gamma (gamma NULL = 1),
+   * up to two consumers, and the per-(row, 16-column tile) sums of squares [M][N/16] */
+  void* emit_a_dev; const float* gamma_a_dev;
+  void* emit_b_dev; const float* gamma_b_dev;
+  float* ssq_out_dev;
+  /* EPI_QKV_ROPE */
+  const float* rope_dev; const int32_t* row_pos_dev; const int32_t* row_slot_dev;
+  float* k_cache_dev; float* v_cache_dev;
+  int32_t n_q_heads, n_kv_heads, cache_len;
+} SmolttsGemm3Args;
+
+int smoltts_k_gemm3(const SmolttsGemm3Args* a, void* stream);
+/* fp32 rows [n_rows][ldx] -> X3 operand(s) (+ sums of squares), for tests and operands without a fused producer */
+int smoltts_k_x3_pack(const float* x_dev, int64_t ldx, int32_t n_rows, int32_t dim, void* x3a_dev,
+                      const float* gamma_a_dev, void* x3b_dev, const float* gamma_b_dev, float* ssq_dev,
+                      void* stream);
+
 /* Measurement hook (bench.py): between begin and end, every GEMM launch whose prologue/epilogue
  * (and N, when n_filter > 0) match is bracketed by a pair of hipEvents on the stream it is launched
  * on.  Use with eager launches only (SMOLTTS_NO_GRAPH=1); events cannot be recorded into a graph
@@ -261,11 +297,12 @@ int smoltts_profile_begin(int32_t prologue, int32_t epilogue, int32_t n_filter, 
 int smoltts_profile_end(float* total_ms, int32_t* n_launches);
 
 /* GQA attention of one query row per (row, kv head) over the slot's cache prefix:
- * keys [max(0, pos+1-window), pos]; q_dev/out_dev [n_rows][n_q_heads*64]. */
+ * keys [max(0, pos+1-window), pos]; q_dev/out_dev [n_rows][n_q_heads*64]; out_x3_dev (optional) receives
+ * the same rows as an X3 operand; either output may be NULL. */
 int smoltts_k_attention(const float* q_dev, const float* k_cache_dev, const float* v_cache_dev,
                         const int32_t* row_pos_dev, const int32_t* row_slot_dev, int32_t n_rows,
                         int32_t n_q_heads, int32_t n_kv_heads, int32_t cache_len, int32_t window,
-                        float* out_dev, void* stream);
+                        float* out_dev, void* out_x3_dev, void* stream);
 
 /* x[r] = E_text[cols[r][0]] + keep * sum_k E_cb[cols[r][1+k] + k*codebook_size] */
 int smoltts_k_embed(const int32_t* cols_dev, int32_t n_rows, int32_t n_code_rows,

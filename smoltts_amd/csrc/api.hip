@@ -28,9 +28,9 @@ int smoltts_k_gemm(const SmolttsGemmArgs* a, void* stream) {
 
 int smoltts_k_attention(const float* q_dev, const float* k_cache_dev, const float* v_cache_dev, const int32_t* row_pos_dev,
                         const int32_t* row_slot_dev, int32_t n_rows, int32_t n_q_heads, int32_t n_kv_heads,
-                        int32_t cache_len, int32_t window, float* out_dev, void* stream) {
+                        int32_t cache_len, int32_t window, float* out_dev, void* out_x3_dev, void* stream) {
   return launch_attention(q_dev, k_cache_dev, v_cache_dev, row_pos_dev, row_slot_dev, n_rows, n_q_heads, n_kv_heads, cache_len,
-                          window, out_dev, (hipStream_t)stream);
+                          window, out_dev, out_x3_dev, (hipStream_t)stream);
 }
 
 int smoltts_k_embed(const int32_t* cols_dev, int32_t n_rows, int32_t n_code_rows, const void* text_emb_dev,
@@ -38,12 +38,12 @@ int smoltts_k_embed(const int32_t* cols_dev, int32_t n_rows, int32_t n_code_rows
                     int32_t sem_start, int32_t sem_end, float* x_dev, void* stream) {
   // table heights are unknown here: the test entry point trusts its caller's indices
   return launch_embed(cols_dev, n_rows, n_code_rows, text_emb_dev, cb_emb_dev, dim, codebook_size, cb_first_offset, mask_mode,
-                      sem_start, sem_end, 0x7fffffff, 0x7fffffff, x_dev, (hipStream_t)stream);
+                      sem_start, sem_end, 0x7fffffff, 0x7fffffff, x_dev, nullptr, (hipStream_t)stream);
 }
 
 int smoltts_k_argmax(const float* logits_dev, int32_t n_rows, int32_t n_cols, int64_t ld, int32_t* ids_dev, int32_t ids_stride,
                      float* margin_dev, void* stream) {
-  return launch_argmax(logits_dev, n_rows, n_cols, ld, ids_dev, ids_stride, margin_dev, nullptr, nullptr, 0, 0, nullptr,
+  return launch_argmax(logits_dev, n_rows, n_cols, ld, ids_dev, ids_stride, margin_dev, nullptr, nullptr, 0, 0, nullptr, nullptr,
                        (hipStream_t)stream);
 }
 

@@ -6,12 +6,14 @@
 // (mlx_inference/.../lm/rq_transformer.py:281-295, lm/cache.py:12-22); Mimi:
 // codec/transformer.py:75-96.  softmax(q.K^T / 8) . V in fp32, head_dim 64.
 //
-// One workgroup (4 waves) per (query row, kv head); the G query heads of the group share every
-// K/V row read.  The cache is fp32 [slot][kv head][cache_len][64], so a key is one 256-byte line
-// pair: 16 lanes x float4 read one key, a wave reads 4 keys per instruction (1 KiB, coalesced).
+// One workgroup per (query row, kv head); the G query heads of the group share every K/V row read.
+// The cache is fp32 [slot][kv head][cache_len][64], so a key is 256 contiguous bytes: 16 lanes x
+// float4 read one key and a wave reads 4 keys per instruction (1 KiB, coalesced), four such loads
+// in flight per wave.  Short caches (the 8-entry depth-transformer cache) run 4 waves, long ones 16.
 // Two passes with the scores parked in LDS (exact softmax: max, exp, sum in a fixed reduction
 // order => deterministic), then P.V with the same lane mapping and a fixed-order cross-wave sum.
-#include "common.h"
+// The result is written as fp32 rows and/or directly as the X3 operand of the following wo GEMM.
+#include "x3.h"
 
 namespace smoltts {
 
@@ -22,6 +24,7 @@ struct AttnDev {
   const int* row_pos;
   const int* row_slot;
   float* out;
+  char* out_x3;
   int n_q_heads, n_kv_heads, cache_len, window, score_cap;
 };
 
@@ -36,20 +39,26 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+constexpr int ATT_UNROLL = 4;
+
 template <int G>
-__global__ __launch_bounds__(256) void attn_kernel(AttnDev p) {
+__global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nwaves = blockDim.x >> 6;
   float* scores = smem;                      // [G][score_cap]
-  float* part = smem + G * p.score_cap;      // [4 waves][G][64]
-  float* stat = part + 4 * G * 64;           // [4][G] scratch, then [G] max, [G] sum
+  float* part = smem + G * p.score_cap;      // [16 waves][G][64]
+  float* stat = part + 16 * G * 64;          // [16][G]
   const int row = blockIdx.x, h = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int kk = lane >> 4, dl = lane & 15;
   const int pos = p.row_pos[row], slot = p.row_slot[row];
   const int HD = p.n_q_heads * 64;
-  float* orow = p.out + (long)row * HD + (h * G) * 64;
   if (pos < 0 || pos >= p.cache_len) {  // nothing cached for this row: defined output, no OOB
-    for (int i = tid; i < G * 64; i += 256) orow[i] = 0.f;
+    for (int i = tid; i < G * 16; i += blockDim.x) {
+      const int k = (h * G + (i >> 4)) * 64 + (i & 15) * 4;
+      if (p.out) *reinterpret_cast<float4*>(p.out + (long)row * HD + k) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.out_x3) x3_emit4(p.out_x3, row, k, HD >> 5, 0.f, 0.f, 0.f, 0.f);
+    }
     return;
   }
   const int j_lo = (p.window > 0 && pos + 1 > p.window) ? pos + 1 - p.window : 0;
@@ -57,6 +66,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnDev p) {
   const long cbase = (((long)slot * p.n_kv_heads + h) * p.cache_len + j_lo) * 64;
   const float* K = p.kc + cbase;
   const float* V = p.vc + cbase;
+  const int step = 4 * nwaves;
 
   float4 qv[G];
 #pragma unroll
@@ -66,22 +76,28 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnDev p) {
   }
 
   // ---- pass 1: scores
-  for (int j0 = wave * 4; j0 < L; j0 += 16) {
-    const int j = j0 + kk;
-    const bool valid = j < L;
-    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) kv = *reinterpret_cast<const float4*>(K + (long)j * 64 + dl * 4);
+  for (int j0 = wave * 4; j0 < L; j0 += step * ATT_UNROLL) {
+    float4 kv[ATT_UNROLL];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      float s = qv[g].x * kv.x;
-      s = fmaf(qv[g].y, kv.y, s);
-      s = fmaf(qv[g].z, kv.z, s);
-      s = fmaf(qv[g].w, kv.w, s);
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      s += __shfl_xor(s, 4);
-      s += __shfl_xor(s, 8);
-      if (valid && dl == 0) scores[g * p.score_cap + j] = s;
+    for (int u = 0; u < ATT_UNROLL; ++u) {
+      const int j = j0 + u * step + kk;
+      kv[u] = j < L ? *reinterpret_cast<const float4*>(K + (long)j * 64 + dl * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < ATT_UNROLL; ++u) {
+      const int j = j0 + u * step + kk;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float s = qv[g].x * kv[u].x;
+        s = fmaf(qv[g].y, kv[u].y, s);
+        s = fmaf(qv[g].z, kv[u].z, s);
+        s = fmaf(qv[g].w, kv[u].w, s);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 8);
+        if (j < L && dl == 0) scores[g * p.score_cap + j] = s;
+      }
     }
   }
   __syncthreads();
@@ -89,21 +105,24 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnDev p) {
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     float m = -INFINITY;
-    for (int j = tid; j < L; j += 256) m = fmaxf(m, scores[g * p.score_cap + j]);
+    for (int j = tid; j < L; j += blockDim.x) m = fmaxf(m, scores[g * p.score_cap + j]);
     m = wave_max(m);
     if (lane == 0) stat[wave * G + g] = m;
   }
   __syncthreads();
   float gmax[G];
 #pragma unroll
-  for (int g = 0; g < G; ++g)
-    gmax[g] = fmaxf(fmaxf(stat[0 * G + g], stat[1 * G + g]), fmaxf(stat[2 * G + g], stat[3 * G + g]));
+  for (int g = 0; g < G; ++g) {
+    float m = stat[g];
+    for (int w = 1; w < nwaves; ++w) m = fmaxf(m, stat[w * G + g]);
+    gmax[g] = m;
+  }
   __syncthreads();
   // ---- exp + sum
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     float s = 0.f;
-    for (int j = tid; j < L; j += 256) {
+    for (int j = tid; j < L; j += blockDim.x) {
       const float e = expf(scores[g * p.score_cap + j] - gmax[g]);
       scores[g * p.score_cap + j] = e;
       s += e;
@@ -112,26 +131,30 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnDev p) {
     if (lane == 0) stat[wave * G + g] = s;
   }
   __syncthreads();
-  float inv[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g)
-    inv[g] = 1.0f / (((stat[0 * G + g] + stat[1 * G + g]) + stat[2 * G + g]) + stat[3 * G + g]);
 
   // ---- pass 2: P.V
   float4 acc[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int j0 = wave * 4; j0 < L; j0 += 16) {
-    const int j = j0 + kk;
-    if (j < L) {
-      const float4 vv = *reinterpret_cast<const float4*>(V + (long)j * 64 + dl * 4);
+  for (int j0 = wave * 4; j0 < L; j0 += step * ATT_UNROLL) {
+    float4 vv[ATT_UNROLL];
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float pj = scores[g * p.score_cap + j];
-        acc[g].x = fmaf(pj, vv.x, acc[g].x);
-        acc[g].y = fmaf(pj, vv.y, acc[g].y);
-        acc[g].z = fmaf(pj, vv.z, acc[g].z);
-        acc[g].w = fmaf(pj, vv.w, acc[g].w);
+    for (int u = 0; u < ATT_UNROLL; ++u) {
+      const int j = j0 + u * step + kk;
+      vv[u] = j < L ? *reinterpret_cast<const float4*>(V + (long)j * 64 + dl * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < ATT_UNROLL; ++u) {
+      const int j = j0 + u * step + kk;
+      if (j < L) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float pj = scores[g * p.score_cap + j];
+          acc[g].x = fmaf(pj, vv[u].x, acc[g].x);
+          acc[g].y = fmaf(pj, vv[u].y, acc[g].y);
+          acc[g].z = fmaf(pj, vv[u].z, acc[g].z);
+          acc[g].w = fmaf(pj, vv[u].w, acc[g].w);
+        }
       }
     }
   }
@@ -143,40 +166,128 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnDev p) {
     if (kk == 0) *reinterpret_cast<float4*>(part + (wave * G + g) * 64 + dl * 4) = a;
   }
   __syncthreads();
-  for (int i = tid; i < G * 64; i += 256) {
-    const int g = i >> 6, d = i & 63;
-    float s = part[(0 * G + g) * 64 + d];
-    s += part[(1 * G + g) * 64 + d];
-    s += part[(2 * G + g) * 64 + d];
-    s += part[(3 * G + g) * 64 + d];
-    float ig = inv[0];
-#pragma unroll
-    for (int gg = 1; gg < G; ++gg) ig = (g == gg) ? inv[gg] : ig;
-    orow[g * 64 + d] = s * ig;
+  if (tid < G * 16) {
+    const int g = tid >> 4, d4 = (tid & 15) * 4;
+    float4 s = *reinterpret_cast<const float4*>(part + g * 64 + d4);
+    float den = stat[g];
+    for (int w = 1; w < nwaves; ++w) {
+      const float4 t = *reinterpret_cast<const float4*>(part + (w * G + g) * 64 + d4);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      den += stat[w * G + g];
+    }
+    const float inv = 1.0f / den;
+    const int k = (h * G + g) * 64 + d4;
+    if (p.out) *reinterpret_cast<float4*>(p.out + (long)row * HD + k) = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+    if (p.out_x3) x3_emit4(p.out_x3, row, k, HD >> 5, s.x * inv, s.y * inv, s.z * inv, s.w * inv);
   }
 }
 
-int launch_attention(const float* q, const float* kc, const float* vc, const int32_t* row_pos,
-                     const int32_t* row_slot, int n_rows, int n_q_heads, int n_kv_heads,
-                     int cache_len, int window, float* out, hipStream_t stream) {
-  ST_REQUIRE(q && kc && vc && row_pos && row_slot && out, SMOLTTS_E_INVALID, "attention: null pointer");
+// Caches of at most 16 entries (the depth transformer's per-frame cache, lm/generate.py:112): one wave
+// per (row, kv head), all K/V rows loaded up front, no LDS and no barrier -- the kernel is a single
+// memory round trip plus wave shuffles.
+template <int G>
+__global__ __launch_bounds__(256) void attn_short_kernel(AttnDev p, int n_pairs) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int kk = lane >> 4, dl = lane & 15;
+  const int pair = blockIdx.x * 4 + wave;
+  if (pair >= n_pairs) return;
+  const int row = pair / p.n_kv_heads, h = pair - row * p.n_kv_heads;
+  const int pos = p.row_pos[row], slot = p.row_slot[row];
+  const int HD = p.n_q_heads * 64;
+  const bool ok = pos >= 0 && pos < p.cache_len;
+  const int j_lo = (ok && p.window > 0 && pos + 1 > p.window) ? pos + 1 - p.window : 0;
+  const int L = ok ? pos + 1 - j_lo : 0;
+  const long cbase = (((long)slot * p.n_kv_heads + h) * p.cache_len + j_lo) * 64;
+  float4 kv[4], vv[4], qv[G];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int j = u * 4 + kk;
+    const bool v = j < L;
+    kv[u] = v ? *reinterpret_cast<const float4*>(p.kc + cbase + (long)j * 64 + dl * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    vv[u] = v ? *reinterpret_cast<const float4*>(p.vc + cbase + (long)j * 64 + dl * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const float4 t = *reinterpret_cast<const float4*>(p.q + (long)row * HD + (h * G + g) * 64 + dl * 4);
+    qv[g] = make_float4(t.x * 0.125f, t.y * 0.125f, t.z * 0.125f, t.w * 0.125f);
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float s[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float t = qv[g].x * kv[u].x;
+      t = fmaf(qv[g].y, kv[u].y, t);
+      t = fmaf(qv[g].z, kv[u].z, t);
+      t = fmaf(qv[g].w, kv[u].w, t);
+      t += __shfl_xor(t, 1);
+      t += __shfl_xor(t, 2);
+      t += __shfl_xor(t, 4);
+      t += __shfl_xor(t, 8);
+      s[u] = t;
+      if (u * 4 + kk < L) mx = fmaxf(mx, t);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float den = 0.f;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float e = (u * 4 + kk < L) ? expf(s[u] - mx) : 0.f;
+      den += e;
+      a.x = fmaf(e, vv[u].x, a.x); a.y = fmaf(e, vv[u].y, a.y); a.z = fmaf(e, vv[u].z, a.z); a.w = fmaf(e, vv[u].w, a.w);
+    }
+    den += __shfl_xor(den, 16);
+    den += __shfl_xor(den, 32);
+    a.x += __shfl_xor(a.x, 16); a.y += __shfl_xor(a.y, 16); a.z += __shfl_xor(a.z, 16); a.w += __shfl_xor(a.w, 16);
+    a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
+    if (kk == 0) {
+      const float inv = L > 0 ? 1.0f / den : 0.f;
+      const int k = (h * G + g) * 64 + dl * 4;
+      if (p.out) *reinterpret_cast<float4*>(p.out + (long)row * HD + k) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+      if (p.out_x3) x3_emit4(p.out_x3, row, k, HD >> 5, a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+    }
+  }
+}
+
+int launch_attention(const float* q, const float* kc, const float* vc, const int32_t* row_pos, const int32_t* row_slot,
+                     int n_rows, int n_q_heads, int n_kv_heads, int cache_len, int window, float* out, void* out_x3,
+                     hipStream_t stream) {
+  ST_REQUIRE(q && kc && vc && row_pos && row_slot && (out || out_x3), SMOLTTS_E_INVALID, "attention: null pointer");
   ST_REQUIRE(n_rows > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0 && cache_len > 0, SMOLTTS_E_INVALID,
              "attention: bad shape rows=%d q_heads=%d kv_heads=%d cache_len=%d", n_rows, n_q_heads, n_kv_heads, cache_len);
   const int G = n_q_heads / n_kv_heads;
-  AttnDev d{q, kc, vc, row_pos, row_slot, out, n_q_heads, n_kv_heads, cache_len, window, 0};
+  AttnDev d{q, kc, vc, row_pos, row_slot, out, (char*)out_x3, n_q_heads, n_kv_heads, cache_len, window, 0};
   d.score_cap = (window > 0 && window < cache_len) ? window : cache_len;
   d.score_cap = (d.score_cap + 3) & ~3;
-  const size_t lds = ((size_t)G * d.score_cap + 4 * G * 64 + 4 * G + 16) * sizeof(float);
+  const int nwaves = d.score_cap <= 64 ? 4 : 16;
+  const size_t lds = ((size_t)G * d.score_cap + 16 * G * 64 + 16 * G + 16) * sizeof(float);
   ST_REQUIRE(lds <= 150 * 1024, SMOLTTS_E_CAPACITY, "attention: %zu bytes of LDS needed for %d keys x %d heads", lds,
              d.score_cap, G);
-  ST_REQUIRE(n_rows <= 0x7fffffff && n_kv_heads <= 65535, SMOLTTS_E_INVALID, "attention: grid too large");
+  ST_REQUIRE(n_kv_heads <= 65535, SMOLTTS_E_INVALID, "attention: grid too large");
+  if (cache_len <= 16) {
+    const int n_pairs = n_rows * n_kv_heads;
+    const dim3 sgrid((n_pairs + 3) / 4);
+    switch (G) {
+      case 1: hipLaunchKernelGGL(attn_short_kernel<1>, sgrid, dim3(256), 0, stream, d, n_pairs); break;
+      case 2: hipLaunchKernelGGL(attn_short_kernel<2>, sgrid, dim3(256), 0, stream, d, n_pairs); break;
+      case 3: hipLaunchKernelGGL(attn_short_kernel<3>, sgrid, dim3(256), 0, stream, d, n_pairs); break;
+      case 4: hipLaunchKernelGGL(attn_short_kernel<4>, sgrid, dim3(256), 0, stream, d, n_pairs); break;
+      default:
+        set_error("attention: GQA group size %d not instantiated (1..4)", G);
+        return SMOLTTS_E_INVALID;
+    }
+    ST_CHECK_HIP(hipGetLastError());
+    return SMOLTTS_OK;
+  }
   const dim3 grid(n_rows, n_kv_heads);
-#define ST_ATTN(GG)                                                                           \
+#define ST_ATTN(GG)                                                                          \
   case GG:                                                                                    \
     if (lds > 64 * 1024)                                                                      \
       ST_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<GG>,                          \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(attn_kernel<GG>, grid, dim3(256), lds, stream, d);                     \
+    hipLaunchKernelGGL(attn_kernel<GG>, grid, dim3(nwaves * 64), lds, stream, d);             \
     break;
   switch (G) {
     ST_ATTN(1)

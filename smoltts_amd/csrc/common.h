@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include <string>
 
 #include "../../include/smoltts_hip.h"
@@ -41,19 +42,33 @@ void set_error(const char* fmt, ...);
 __device__ __forceinline__ float bf16_lo(uint32_t dw) { return __uint_as_float(dw << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t dw) { return __uint_as_float(dw & 0xffff0000u); }
 
+// Host-side description of where a producer of the residual stream publishes it for the next GEMM(s)
+// (device form: EmitDev in x3.h).
+struct EmitArgs {
+  void* x3a;
+  const float* gamma_a;
+  void* x3b;
+  const float* gamma_b;
+  float* ssq;
+};
+
 // Launchers implemented across the .hip files (all asynchronous on `stream`).
 int launch_gemm(const SmolttsGemmArgs& a, hipStream_t stream);
+int launch_gemm3(const SmolttsGemm3Args& a, hipStream_t stream);
+int launch_x3_pack(const float* x, int64_t ldx, int n_rows, int dim, void* x3a, const float* gamma_a, void* x3b,
+                   const float* gamma_b, float* ssq, hipStream_t stream);
 int launch_attention(const float* q, const float* kc, const float* vc, const int32_t* row_pos,
                      const int32_t* row_slot, int n_rows, int n_q_heads, int n_kv_heads,
-                     int cache_len, int window, float* out, hipStream_t stream);
+                     int cache_len, int window, float* out, void* out_x3, hipStream_t stream);
 int launch_embed(const int32_t* cols, int n_rows, int n_code_rows, const void* text_emb,
                  const void* cb_emb, int dim, int codebook_size, int cb_first_offset, int mask_mode,
-                 int sem_start, int sem_end, int text_rows, int cb_rows, float* x, hipStream_t stream);
+                 int sem_start, int sem_end, int text_rows, int cb_rows, float* x, const EmitArgs* emit,
+                 hipStream_t stream);
 // argmax over each row; writes ids[r*ids_stride]; optionally (emb != nullptr) gathers
 // emb[(id + emb_row_offset)] (bf16 row-major, `dim` wide) into xnext[r].
 int launch_argmax(const float* logits, int n_rows, int n_cols, int64_t ld, int32_t* ids,
                   int ids_stride, float* margin, const int32_t* margin_mask, const void* emb,
-                  int emb_row_offset, int dim, float* xnext, hipStream_t stream);
+                  int emb_row_offset, int dim, float* xnext, const EmitArgs* emit, hipStream_t stream);
 int launch_layernorm(const float* x, const float* w, const float* b, int n_rows, int dim, float eps,
                      float* out, hipStream_t stream);
 int launch_gather_rows(const float* src, const int32_t* idx, int n, int dim, float* dst,

@@ -43,7 +43,17 @@ struct GemmDev {
   float* kc;
   float* vc;
   int n_q_heads, n_kv_heads, cache_len;
+  unsigned long long* stamps;  // diagnostic build aid (SMOLTTS debug API); nullptr in production
 };
+
+// cycle stamps of workgroup (0,0): [wave][slot] = {s_memtime, s_memrealtime}
+#define STAMP(k)                                                                              \
+  do {                                                                                        \
+    if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {                        \
+      p.stamps[(wave * 8 + (k)) * 2] = clock64();                                             \
+      p.stamps[(wave * 8 + (k)) * 2 + 1] = wall_clock64();                                    \
+    }                                                                                         \
+  } while (0)
 
 __device__ __forceinline__ long row_off(int m, int rpb, long ld, long bstride) {
   if (rpb <= 0) return (long)m * ld;
@@ -78,6 +88,7 @@ __global__ __launch_bounds__(MT >= 4 ? 512 : 1024) void gemm_kernel(GemmDev p) {
     xrow[mt] = p.x + (xv[mt] ? row_off(m, p.rows_per_batch, p.ldx, p.x_bstride) : 0);
   }
   const char* wt = p.w + (size_t)nt * nchunks * WBYTES + lane * 16;
+  STAMP(0);
 
   for (int c0 = wave; c0 < nchunks; c0 += nwaves * U) {
     uint4 wraw[U][WF32 ? 2 : 1];
@@ -154,13 +165,14 @@ __global__ __launch_bounds__(MT >= 4 ? 512 : 1024) void gemm_kernel(GemmDev p) {
     }
   }
 
-  // ---- cross-wave reduction (fixed order), layout red[wave][mt][reg][lane]
-  float* red = smem;
+  STAMP(1);
+  // ---- cross-wave reduction (fixed order): red4[wave][mt][lane] holds the lane's 4 accumulators
+  STAMP(2);
+  float4* red4 = reinterpret_cast<float4*>(smem);
   float* ssred = smem + nwaves * MT * 256;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) red[((wave * MT + mt) * 4 + i) * 64 + lane] = acc[mt][i];
+    red4[(wave * MT + mt) * 64 + lane] = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
     if (PRO == SMOLTTS_PRO_RMSNORM) {
       float s = ss[mt];
       s += __shfl_xor(s, 16);
@@ -168,21 +180,34 @@ __global__ __launch_bounds__(MT >= 4 ? 512 : 1024) void gemm_kernel(GemmDev p) {
       if (lane < 16) ssred[(wave * MT + mt) * 16 + lane] = s;
     }
   }
+  STAMP(3);
   __syncthreads();
+  STAMP(4);
   if (tid >= 64 * MT) return;
   const int mt = tid >> 6;  // lane, r, q keep their meaning
   const int m = (mg * MT + mt) * 16 + r;
   if (m >= p.M) return;
-  float v[4];
+  // all partials are fetched before the first add (one LDS round trip); waves beyond nwaves add +0
+  float4 part[16];
+  float sp[16];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float s = 0.f;
-    for (int w = 0; w < nwaves; ++w) s += red[((w * MT + mt) * 4 + i) * 64 + lane];
-    v[i] = s;
+  for (int w = 0; w < 16; ++w) {
+    const int ww = w < nwaves ? w : 0;
+    part[w] = red4[(ww * MT + mt) * 64 + lane];
+    if (PRO == SMOLTTS_PRO_RMSNORM) sp[w] = ssred[(ww * MT + mt) * 16 + r];
+  }
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const bool on = w < nwaves;
+    v[0] += on ? part[w].x : 0.f;
+    v[1] += on ? part[w].y : 0.f;
+    v[2] += on ? part[w].z : 0.f;
+    v[3] += on ? part[w].w : 0.f;
+    if (PRO == SMOLTTS_PRO_RMSNORM) tot += on ? sp[w] : 0.f;
   }
   if (PRO == SMOLTTS_PRO_RMSNORM) {
-    float tot = 0.f;
-    for (int w = 0; w < nwaves; ++w) tot += ssred[(w * MT + mt) * 16 + r];
     const float rstd = 1.0f / sqrtf(tot / (float)p.K + p.eps);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] *= rstd;
@@ -235,6 +260,7 @@ __global__ __launch_bounds__(MT >= 4 ? 512 : 1024) void gemm_kernel(GemmDev p) {
       *reinterpret_cast<float4*>(base + (((long)slot * p.n_kv_heads + h) * p.cache_len + pos) * 64 + d) = o;
     }
   }
+  STAMP(5);
 }
 
 template <bool WF32, int MT, int U, int PRO, int EPI>
@@ -263,15 +289,25 @@ struct ProfileState {
 }  // namespace
 
 static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream);
+static unsigned long long* g_stamps = nullptr;
+
+// shared with gemm3.hip: returns the event-pair index to close with profile_hook_end, or -1
+int profile_hook_begin(int prologue, int epilogue, int N, hipStream_t stream) {
+  const bool hit = g_prof.on && prologue == g_prof.pro && epilogue == g_prof.epi && (g_prof.n <= 0 || N == g_prof.n) &&
+                   g_prof.used < g_prof.cap;
+  if (!hit) return -1;
+  const int i = g_prof.used++;
+  (void)hipEventRecord(g_prof.ev[2 * i], stream);
+  return i;
+}
+void profile_hook_end(int i, hipStream_t stream) {
+  if (i >= 0) (void)hipEventRecord(g_prof.ev[2 * i + 1], stream);
+}
 
 int launch_gemm(const SmolttsGemmArgs& a, hipStream_t stream) {
-  const bool hit = g_prof.on && a.prologue == g_prof.pro && a.epilogue == g_prof.epi && (g_prof.n <= 0 || a.N == g_prof.n) &&
-                   g_prof.used < g_prof.cap;
-  if (!hit) return launch_gemm_impl(a, stream);
-  const int i = g_prof.used++;
-  ST_CHECK_HIP(hipEventRecord(g_prof.ev[2 * i], stream));
+  const int i = profile_hook_begin(a.prologue, a.epilogue, a.N, stream);
   const int rc = launch_gemm_impl(a, stream);
-  ST_CHECK_HIP(hipEventRecord(g_prof.ev[2 * i + 1], stream));
+  profile_hook_end(i, stream);
   return rc;
 }
 
@@ -296,6 +332,7 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
   d.rope = a.rope_dev; d.row_pos = a.row_pos_dev; d.row_slot = a.row_slot_dev;
   d.kc = a.k_cache_dev; d.vc = a.v_cache_dev; d.n_q_heads = a.n_q_heads; d.n_kv_heads = a.n_kv_heads;
   d.cache_len = a.cache_len;
+  d.stamps = g_stamps;
   const int nchunks = a.K / 32;
   // waves split K: keep ~3 chunks per wave, at most 16 waves
   int nwaves = (nchunks + 2) / 3;
@@ -338,6 +375,12 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
 }  // namespace smoltts
 
 extern "C" {
+
+// undocumented diagnostic: device buffer of 16 waves x 8 slots x 2 u64 receiving cycle stamps
+int smoltts_debug_set_stamps(void* buf_dev) {
+  smoltts::g_stamps = (unsigned long long*)buf_dev;
+  return SMOLTTS_OK;
+}
 
 int smoltts_profile_begin(int32_t prologue, int32_t epilogue, int32_t n_filter, int32_t max_launches) {
   using namespace smoltts;

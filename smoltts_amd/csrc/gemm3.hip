@@ -1,0 +1,354 @@
+// bf16-MFMA skinny GEMM of the DualAR transformer:  out[M,N] = epi( X[M,K] . W[N,K]^T ), where the
+// activation operand arrives pre-split in the X3 format (x3.h: hi+mid+lo bf16 pieces == the fp32
+// value, already multiplied by the RMSNorm weight) and the bf16 weights in T16x32 tiles.
+//
+// Reference ops: the nn.Linear calls of modeling/model/rq_transformer.py (wqkv :545, wo :570,
+// w1/w3/w2 :582, tied head :253, depthwise head :598) with their RMSNorm (:607-613), RoPE (:627-640),
+// SiLU-gate and residual adds fused around them.
+//
+// Why this shape (measured on MI355X, tools/microbench_gemm.py): at 32 rows the fp32-input MFMA
+// (gemm.hip) is matrix-pipe bound (8 x 32-cycle MFMAs per 32-k chunk and 16-row tile) and every
+// workgroup re-converts the same activations.  Here one chunk costs 3 x 16-cycle bf16 MFMAs with no
+// VALU work at all on the operand path: both fragments are loaded with one coalesced 16-byte-per-
+// lane load each and fed straight to v_mfma_f32_16x16x32_bf16.  Products are exact (8-bit x 8-bit
+// significands), accumulation is fp32, so results stay within fp32 rounding of the CPU oracle.
+//
+// Work split: workgroup = T adjacent 16-column weight tiles x MT 16-row tiles x all of K; its
+// waves split K chunk-wise, keep the activation fragments in registers across the T tiles, and
+// their partial tiles are summed through LDS in fixed wave order (deterministic, no atomics).
+// RMSNorm: the producer of x also publishes per-(row, 16-column) partial sums of squares; the
+// consumer adds them in fixed order and scales its result rows by rsqrt(mean + eps).
+// Epilogues write what the *next* kernel consumes: fp32 residual stream + X3 operand(s) + partial
+// sums of squares (wo / w2), the SwiGLU product as X3 (w1|w3), RoPE'd q + KV-cache rows (wqkv).
+#include <stdlib.h>
+
+#include "x3.h"
+
+namespace smoltts {
+
+struct Gemm3Dev {
+  const char* w;
+  const char* x3;
+  int M, N, K;
+  const float* ssq_in;
+  float eps;
+  const float* bias;
+  const float* resid;
+  float* out;
+  long ldo;
+  char* x3_out;  // SWIGLU
+  EmitDev emit;
+  const float* rope;
+  const int* row_pos;
+  const int* row_slot;
+  float* kc;
+  float* vc;
+  int n_q_heads, n_kv_heads, cache_len;
+};
+
+__device__ __forceinline__ float silu3(float x) { return x / (1.f + expf(-x)); }
+
+template <int MT, int T, int U, int EPI>
+__global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nwaves = blockDim.x >> 6;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int ng = blockIdx.x, mg = blockIdx.y;
+  const int nchunks = p.K >> 5;
+  constexpr bool kResid = EPI == SMOLTTS_EPI_RESID;
+  constexpr bool kEmits = EPI == SMOLTTS_EPI_RESID || EPI == SMOLTTS_EPI_STORE;
+  constexpr bool kRope = EPI == SMOLTTS_EPI_QKV_ROPE;
+
+  // ---- epilogue inputs of the waves that will finish the tiles (waves < MT): every load is issued
+  //      here, ahead of the operand stream, so that the tail of the kernel waits on nothing
+  const bool fin = wave < MT;
+  const int m = (mg * MT + wave) * 16 + r;  // meaningful for fin waves only
+  const bool mvalid = fin && m < p.M;
+  int pos = 0, slot = 0;
+  float ssv[16];
+  float4 rr[T], bb[T], ga[T], gb[T];
+  if (fin) {
+    if (kRope && mvalid) { pos = p.row_pos[m]; slot = p.row_slot[m]; }
+    const int nt_in = p.K >> 4;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int i = q + 4 * j;
+      ssv[j] = (p.ssq_in != nullptr && mvalid && i < nt_in) ? p.ssq_in[(size_t)m * nt_in + i] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int n0 = (ng * T + t) * 16 + q * 4;
+      const bool valid = mvalid && n0 < p.N;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      rr[t] = (kResid && valid) ? *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldo + n0) : z;
+      bb[t] = (p.bias != nullptr && valid) ? *reinterpret_cast<const float4*>(p.bias + n0) : z;
+      ga[t] = (kEmits && p.emit.x3a && p.emit.gamma_a && valid) ? *reinterpret_cast<const float4*>(p.emit.gamma_a + n0)
+                                                                : make_float4(1.f, 1.f, 1.f, 1.f);
+      gb[t] = (kEmits && p.emit.x3b && p.emit.gamma_b && valid) ? *reinterpret_cast<const float4*>(p.emit.gamma_b + n0)
+                                                                : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+  }
+
+  f32x4 acc[T][MT];
+  const char* xb[MT];
+  bool xv[MT];
+  const char* wb[T];
+  bool wv[T];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int mtile = mg * MT + mt;
+    xv[mt] = mtile * 16 < p.M;
+    xb[mt] = p.x3 + (size_t)mtile * nchunks * 3072 + lane * 16;
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int ntile = ng * T + t;
+    wv[t] = ntile * 16 < p.N;
+    wb[t] = p.w + (size_t)ntile * nchunks * 1024 + lane * 16;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  for (int c0 = wave; c0 < nchunks; c0 += nwaves * U) {
+    uint4 xf[U][MT][3];
+    uint4 wf[U][T];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * nwaves;
+      const bool cv = c < nchunks;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        wf[u][t] = (cv && wv[t]) ? *reinterpret_cast<const uint4*>(wb[t] + (size_t)c * 1024) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          xf[u][mt][pc] = (cv && xv[mt]) ? *reinterpret_cast<const uint4*>(xb[mt] + (size_t)c * 3072 + pc * 1024)
+                                         : make_uint4(0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const bf16x8_t a = __builtin_bit_cast(bf16x8_t, wf[u][t]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc)
+            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8_t, xf[u][mt][pc]), acc[t][mt], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // RoPE rows of the finishing waves (needs pos, which arrived long ago); in flight across the barrier
+  float4 cs[T];
+  if (kRope && fin) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int n0 = (ng * T + t) * 16 + q * 4;
+      const bool rot = mvalid && n0 < (p.n_q_heads + p.n_kv_heads) * 64 && pos >= 0;
+      cs[t] = rot ? *reinterpret_cast<const float4*>(p.rope + ((long)pos * 32 + ((n0 & 63) >> 1)) * 2) : make_float4(1.f, 0.f, 1.f, 0.f);
+    }
+  }
+
+  // ---- cross-wave reduction: red4[((wave*T + t)*MT + mt)*64 + lane]
+  float4* red4 = reinterpret_cast<float4*>(smem);
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      red4[((wave * T + t) * MT + mt) * 64 + lane] = make_float4(acc[t][mt][0], acc[t][mt][1], acc[t][mt][2], acc[t][mt][3]);
+  }
+  __syncthreads();
+  if (!fin) return;
+  const int mt = wave;  // lane, r, q keep their meaning
+
+  // RMSNorm row scale from the producer's partial sums of squares (fixed order)
+  float rstd = 1.f;
+  if (p.ssq_in != nullptr) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += ssv[j];
+    const int nt_in = p.K >> 4;
+    if (nt_in > 64 && mvalid)
+      for (int i = 64 + q; i < nt_in; i += 4) s += p.ssq_in[(size_t)m * nt_in + i];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    rstd = 1.0f / sqrtf(s / (float)p.K + p.eps);
+  }
+
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    float4 part[16];
+#pragma unroll
+    for (int w = 0; w < 16; ++w) part[w] = red4[(((w < nwaves ? w : 0) * T + t) * MT + mt) * 64 + lane];
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const bool on = w < nwaves;
+      v[0] += on ? part[w].x : 0.f;
+      v[1] += on ? part[w].y : 0.f;
+      v[2] += on ? part[w].z : 0.f;
+      v[3] += on ? part[w].w : 0.f;
+    }
+    const int ntile = ng * T + t;
+    const int n0 = ntile * 16 + q * 4;
+    const bool valid = mvalid && n0 < p.N;  // N % 4 == 0
+    v[0] = v[0] * rstd + bb[t].x; v[1] = v[1] * rstd + bb[t].y; v[2] = v[2] * rstd + bb[t].z; v[3] = v[3] * rstd + bb[t].w;
+
+    if (EPI == SMOLTTS_EPI_STORE || EPI == SMOLTTS_EPI_RESID) {
+      if (kResid) { v[0] += rr[t].x; v[1] += rr[t].y; v[2] += rr[t].z; v[3] += rr[t].w; }
+      if (valid) {
+        *reinterpret_cast<float4*>(p.out + (long)m * p.ldo + n0) = make_float4(v[0], v[1], v[2], v[3]);
+        if (p.emit.x3a) x3_emit4(p.emit.x3a, m, n0, p.N >> 5, v[0] * ga[t].x, v[1] * ga[t].y, v[2] * ga[t].z, v[3] * ga[t].w);
+        if (p.emit.x3b) x3_emit4(p.emit.x3b, m, n0, p.N >> 5, v[0] * gb[t].x, v[1] * gb[t].y, v[2] * gb[t].z, v[3] * gb[t].w);
+      }
+      if (p.emit.ssq) {  // all 64 lanes take part in the shuffles
+        float s = valid ? ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) : 0.f;
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (q == 0 && mvalid && ntile * 16 < p.N) p.emit.ssq[(size_t)m * (p.N >> 4) + ntile] = s;
+      }
+    } else if (EPI == SMOLTTS_EPI_SWIGLU) {
+      if (valid) x3_emit2(p.x3_out, m, n0 >> 1, p.N >> 6, silu3(v[0]) * v[1], silu3(v[2]) * v[3]);
+    } else if (EPI == SMOLTTS_EPI_QKV_ROPE) {
+      if (valid) {
+        const int qd = p.n_q_heads * 64, kd = p.n_kv_heads * 64;
+        if (n0 < qd + kd) {
+          const float o0 = v[0] * cs[t].x - v[1] * cs[t].y, o1 = v[1] * cs[t].x + v[0] * cs[t].y;
+          const float o2 = v[2] * cs[t].z - v[3] * cs[t].w, o3 = v[3] * cs[t].z + v[2] * cs[t].w;
+          v[0] = o0; v[1] = o1; v[2] = o2; v[3] = o3;
+        }
+        const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (n0 < qd) {
+          *reinterpret_cast<float4*>(p.out + (long)m * p.ldo + n0) = o;
+        } else if (pos >= 0 && pos < p.cache_len) {
+          const int nn = n0 - qd;
+          float* base = nn < kd ? p.kc : p.vc;
+          const int h = (nn < kd ? nn : nn - kd) >> 6, d = nn & 63;
+          *reinterpret_cast<float4*>(base + (((long)slot * p.n_kv_heads + h) * p.cache_len + pos) * 64 + d) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int MT, int T, int U, int EPI>
+static int launch3_one(const Gemm3Dev& d, int nwaves, hipStream_t stream) {
+  const int ntiles = (d.N + 15) / 16;
+  if (nwaves < MT) nwaves = MT;  // one finishing wave per 16-row tile
+  const dim3 grid((ntiles + T - 1) / T, (d.M + 16 * MT - 1) / (16 * MT));
+  const size_t lds = (size_t)nwaves * T * MT * 1024;
+  hipLaunchKernelGGL((gemm3_kernel<MT, T, U, EPI>), grid, dim3(nwaves * 64), lds, stream, d);
+  ST_CHECK_HIP(hipGetLastError());
+  return SMOLTTS_OK;
+}
+
+// Decomposition: enough workgroups to spread the weight stream over the chip (16-row tiles go to
+// separate workgroups when there are few column tiles), all of a wave's loads in flight at once.
+template <int EPI>
+static int launch3_epi(const Gemm3Dev& d, hipStream_t stream) {
+  const int nchunks = d.K / 32, ntiles = (d.N + 15) / 16;
+  int nwaves = (nchunks + 2) / 3;
+  nwaves = nwaves < 1 ? 1 : (nwaves > 8 ? 8 : nwaves);  // <= 512 threads: 256 VGPRs per lane
+  const int cpw = (nchunks + nwaves - 1) / nwaves;  // chunks per wave
+  if (d.M > 32)  // prefill: 64 rows per workgroup, weights re-used from registers
+    return launch3_one<4, 1, 2, EPI>(d, nwaves < 4 ? 4 : nwaves, stream);
+  const bool two_row_tiles = d.M > 16 && ntiles >= 128;
+  if (two_row_tiles) {
+    if (ntiles >= 320) return launch3_one<2, 2, 3, EPI>(d, nwaves, stream);
+    return launch3_one<2, 1, 3, EPI>(d, nwaves, stream);
+  }
+  if (ntiles >= 512) return launch3_one<1, 2, 3, EPI>(d, nwaves, stream);
+  if (cpw > 6) return launch3_one<1, 1, 12, EPI>(d, nwaves, stream);
+  if (cpw > 3) return launch3_one<1, 1, 6, EPI>(d, nwaves, stream);
+  return launch3_one<1, 1, 3, EPI>(d, nwaves, stream);
+}
+
+int profile_hook_begin(int prologue, int epilogue, int N, hipStream_t stream);  // gemm.hip
+void profile_hook_end(int i, hipStream_t stream);
+static int launch_gemm3_impl(const SmolttsGemm3Args& a, hipStream_t stream);
+
+int launch_gemm3(const SmolttsGemm3Args& a, hipStream_t stream) {
+  // the measurement hook sees a normed input as the RMSNorm prologue
+  const int i = profile_hook_begin(a.ssq_in_dev ? SMOLTTS_PRO_RMSNORM : SMOLTTS_PRO_NONE, a.epilogue, a.N, stream);
+  const int rc = launch_gemm3_impl(a, stream);
+  profile_hook_end(i, stream);
+  return rc;
+}
+
+static int launch_gemm3_impl(const SmolttsGemm3Args& a, hipStream_t stream) {
+  ST_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 32 == 0 && a.N % 4 == 0, SMOLTTS_E_INVALID,
+             "gemm3: bad shape M=%d N=%d K=%d (K %% 32, N %% 4)", a.M, a.N, a.K);
+  ST_REQUIRE(a.w_dev && a.x3_dev, SMOLTTS_E_INVALID, "gemm3: null operand");
+  ST_REQUIRE(a.ssq_in_dev == nullptr || a.K % 64 == 0, SMOLTTS_E_INVALID, "gemm3: normed input needs K %% 64 == 0");
+  Gemm3Dev d;
+  memset(&d, 0, sizeof(d));
+  d.w = (const char*)a.w_dev; d.x3 = (const char*)a.x3_dev; d.M = a.M; d.N = a.N; d.K = a.K;
+  d.ssq_in = a.ssq_in_dev; d.eps = a.eps; d.bias = a.bias_dev; d.resid = a.resid_dev; d.out = a.out_dev; d.ldo = a.ldo;
+  d.x3_out = (char*)a.x3_out_dev;
+  d.emit.x3a = (char*)a.emit_a_dev; d.emit.gamma_a = a.gamma_a_dev; d.emit.x3b = (char*)a.emit_b_dev;
+  d.emit.gamma_b = a.gamma_b_dev; d.emit.ssq = a.ssq_out_dev;
+  d.rope = a.rope_dev; d.row_pos = a.row_pos_dev; d.row_slot = a.row_slot_dev; d.kc = a.k_cache_dev; d.vc = a.v_cache_dev;
+  d.n_q_heads = a.n_q_heads; d.n_kv_heads = a.n_kv_heads; d.cache_len = a.cache_len;
+  switch (a.epilogue) {
+    case SMOLTTS_EPI_STORE:
+      ST_REQUIRE(a.out_dev && a.ldo % 4 == 0, SMOLTTS_E_INVALID, "gemm3: STORE needs out/ldo");
+      ST_REQUIRE(!(a.emit_a_dev || a.emit_b_dev || a.ssq_out_dev) || a.N % 64 == 0, SMOLTTS_E_INVALID, "gemm3: emission needs N %% 64 == 0");
+      return launch3_epi<SMOLTTS_EPI_STORE>(d, stream);
+    case SMOLTTS_EPI_RESID:
+      ST_REQUIRE(a.out_dev && a.resid_dev && a.ldo % 4 == 0, SMOLTTS_E_INVALID, "gemm3: RESID needs out/resid/ldo");
+      ST_REQUIRE(!(a.emit_a_dev || a.emit_b_dev || a.ssq_out_dev) || a.N % 64 == 0, SMOLTTS_E_INVALID, "gemm3: emission needs N %% 64 == 0");
+      return launch3_epi<SMOLTTS_EPI_RESID>(d, stream);
+    case SMOLTTS_EPI_SWIGLU:
+      ST_REQUIRE(a.x3_out_dev && a.N % 64 == 0, SMOLTTS_E_INVALID, "gemm3: SWIGLU needs x3_out and N %% 64 == 0");
+      return launch3_epi<SMOLTTS_EPI_SWIGLU>(d, stream);
+    case SMOLTTS_EPI_QKV_ROPE:
+      ST_REQUIRE(a.rope_dev && a.row_pos_dev && a.row_slot_dev && a.k_cache_dev && a.v_cache_dev && a.out_dev &&
+                     a.N == (a.n_q_heads + 2 * a.n_kv_heads) * 64 && a.cache_len > 0 && a.ldo % 4 == 0,
+                 SMOLTTS_E_INVALID, "gemm3: QKV_ROPE arguments inconsistent");
+      return launch3_epi<SMOLTTS_EPI_QKV_ROPE>(d, stream);
+    default:
+      set_error("gemm3: unsupported epilogue %d", a.epilogue);
+      return SMOLTTS_E_INVALID;
+  }
+}
+
+// ---- fp32 rows -> X3 (+ ssq): test / bring-up entry for operands that no fused producer writes
+__global__ __launch_bounds__(256) void x3_pack_kernel(const float* x, long ldx, int dim, EmitDev e) {
+  __shared__ float sh4[4];
+  const int m = blockIdx.x;
+  float ss = 0.f;
+  for (int k = threadIdx.x * 4; k < dim; k += 256 * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(x + (long)m * ldx + k);
+    ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    emit_x4(e, m, k, dim >> 5, v.x, v.y, v.z, v.w);
+  }
+  emit_row_ssq(e, m, dim, ss, sh4);
+}
+
+int launch_x3_pack(const float* x, int64_t ldx, int n_rows, int dim, void* x3a, const float* gamma_a, void* x3b,
+                   const float* gamma_b, float* ssq, hipStream_t stream) {
+  ST_REQUIRE(x && n_rows > 0 && dim % 32 == 0 && ldx % 4 == 0, SMOLTTS_E_INVALID, "x3_pack: bad arguments");
+  EmitDev e{(char*)x3a, gamma_a, (char*)x3b, gamma_b, ssq};
+  hipLaunchKernelGGL(x3_pack_kernel, dim3(n_rows), dim3(256), 0, stream, x, (long)ldx, dim, e);
+  ST_CHECK_HIP(hipGetLastError());
+  return SMOLTTS_OK;
+}
+
+}  // namespace smoltts
+
+extern "C" {
+int smoltts_k_gemm3(const SmolttsGemm3Args* a, void* stream) {
+  using namespace smoltts;
+  ST_REQUIRE(a, SMOLTTS_E_INVALID, "k_gemm3: null args");
+  return launch_gemm3(*a, (hipStream_t)stream);
+}
+int smoltts_k_x3_pack(const float* x_dev, int64_t ldx, int32_t n_rows, int32_t dim, void* x3a_dev, const float* gamma_a_dev,
+                      void* x3b_dev, const float* gamma_b_dev, float* ssq_dev, void* stream) {
+  return smoltts::launch_x3_pack(x_dev, ldx, n_rows, dim, x3a_dev, gamma_a_dev, x3b_dev, gamma_b_dev, ssq_dev, (hipStream_t)stream);
+}
+}

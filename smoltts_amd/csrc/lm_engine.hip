@@ -6,11 +6,17 @@
 // generate.py:110-141) -> commit of the (1 + n_fast)-high column.  Sampling, the column feedback, the
 // stop rule and the position counters all live on the device, so a frame is a fixed launch sequence that
 // is captured once into a hipGraph and replayed (the reference synchronises with the host 9x per frame).
+//
+// Dataflow between kernels (x3.h): the residual stream x stays fp32; whoever produces x also publishes
+// it as the bf16x3 operand of the next GEMM (times that GEMM's RMSNorm weight) plus partial sums of
+// squares, so each transformer block is exactly five launches:
+//   wqkv GEMM (+RMSNorm scale, RoPE, KV write) -> attention (writes wo's operand) -> wo GEMM (+residual,
+//   publishes w1|w3's operand) -> w1|w3 GEMM (+RMSNorm scale, SwiGLU, writes w2's operand) -> w2 GEMM
+//   (+residual, publishes the next block's / head's operand).
 #include <stdlib.h>
 #include <string.h>
 
 #include <new>
-#include <vector>
 
 #include "common.h"
 
@@ -28,9 +34,11 @@ struct SmolttsSession {
   int B, max_seq, max_rows, max_frames;
   int stop_on_eos;
   // activations
-  float *xr, *qr, *ar, *hr;  // prefill rows: [max_rows][dim | Hq*64 | dim | inter]
-  float *xt, *xf;            // [B][dim], [B][fast_dim]
-  float *qt, *at, *ht;       // decode/tail rows [B][...] sized for max(slow, fast)
+  float *xr, *qr;            // prefill rows: fp32 residual stream [max_rows][dim], q [max_rows][Hq*64]
+  float *xt, *xf;            // decode/tail rows: [B][dim], [B][fast_dim]
+  float* qt;                 // [B][max(Hq, fast Hq)*64]
+  char *x3n, *x3n2, *x3a, *x3h;  // X3 operands: normed stream (2 consumers), attention out, SwiGLU out
+  float* ssq;                // [rows][dim/16] partial sums of squares of the stream
   float* logits;             // [B][max(vocab, codebook)]
   // caches
   float *kc, *vc;            // [n_layer][B][KV][max_seq][64]
@@ -69,17 +77,19 @@ void carve(SmolttsSession* s, char* base, size_t* total) {
   const SmolttsLMConfig& c = s->e->cfg;
   Carver cv{base, 0};
   const size_t B = s->B, R = s->max_rows, H = 1 + c.n_fast;
+  const size_t R16 = (R + 15) / 16 * 16, B16 = (B + 15) / 16 * 16;
   const size_t dq = (size_t)imax(c.n_head, c.fast_n_head) * 64;
   const size_t dmax = imax(c.dim, c.fast_dim), imx = imax(c.inter, c.fast_inter);
   s->xr = cv.take<float>(R * c.dim);
   s->qr = cv.take<float>(R * c.n_head * 64);
-  s->ar = cv.take<float>(R * c.dim);
-  s->hr = cv.take<float>(R * c.inter);
   s->xt = cv.take<float>(B * c.dim);
   s->xf = cv.take<float>(B * c.fast_dim);
   s->qt = cv.take<float>(B * dq);
-  s->at = cv.take<float>(B * dmax);
-  s->ht = cv.take<float>(B * imx);
+  s->x3n = cv.take<char>(R16 * dmax * 6);
+  s->x3n2 = cv.take<char>(B16 * dmax * 6);
+  s->x3a = cv.take<char>(R16 * dmax * 6);
+  s->x3h = cv.take<char>(R16 * imx * 6);
+  s->ssq = cv.take<float>(R16 * (dmax / 16));
   s->logits = cv.take<float>(B * (size_t)imax(c.vocab_size, c.codebook_size));
   const size_t kv = (size_t)c.n_layer * B * c.n_kv_head * s->max_seq * 64;
   s->kc = cv.take<float>(kv);
@@ -128,15 +138,6 @@ __global__ void slot_reset_kernel(int B, int n_slots, const int* slots, const in
   }
 }
 
-// xt[slots[i]] = xr[last_row[i]]
-__global__ __launch_bounds__(256) void scatter_last_kernel(const float* xr, const int* slots, const int* last_row, int dim,
-                                                           float* xt) {
-  const int i = blockIdx.x;
-  const long s = last_row[i], d0 = slots[i];
-  for (int d = threadIdx.x * 4; d < dim; d += 256 * 4)
-    *reinterpret_cast<float4*>(xt + d0 * dim + d) = *reinterpret_cast<const float4*>(xr + s * dim + d);
-}
-
 __global__ void decode_mask_kernel(int B, const int* done, int* mask) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) mask[b] = !done[b];
@@ -161,91 +162,117 @@ __global__ void commit_kernel(int B, int H, int max_frames, int im_end, int stop
   if ((stop_on_eos && new_col[b * H] == im_end) || f + 1 >= max_frames) done[b] = 1;
 }
 
-SmolttsGemmArgs base_gemm(const void* w, const float* x, long ldx, int M, int N, int K) {
-  SmolttsGemmArgs a;
+SmolttsGemm3Args base3(const void* w, const void* x3, int M, int N, int K, int epilogue) {
+  SmolttsGemm3Args a;
   memset(&a, 0, sizeof(a));
-  a.w_dev = w; a.w_is_fp32 = 0; a.x_dev = x; a.ldx = ldx; a.M = M; a.N = N; a.K = K;
+  a.w_dev = w; a.x3_dev = x3; a.M = M; a.N = N; a.K = K; a.epilogue = epilogue;
   return a;
 }
 
-// One pre-norm block (modeling/model/rq_transformer.py:492-501) over `M` rows held in x (in place).
-int run_block(const SmolttsEngine* e, const SmolttsBlockWeights& bw, int dim, int n_head, int n_kv, int inter, float* x,
-              float* q, float* attn, float* h, int M, const int* row_pos, const int* row_slot, const float* rope, float* kc,
-              float* vc, int cache_len, hipStream_t st) {
+// One pre-norm block (modeling/model/rq_transformer.py:492-501) over `M` rows of the fp32 stream x (in place).
+// `in_x3`/ssq: x published for the wqkv GEMM by whoever produced x; `next`: where the block publishes its output.
+int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, int n_head, int n_kv, int inter, float* x,
+              float* q, int M, const int* row_pos, const int* row_slot, const float* rope, float* kc, float* vc,
+              int cache_len, const char* in_x3, const EmitArgs& next, hipStream_t st) {
+  const SmolttsEngine* e = s->e;
   const char* A = e->arena;
   const float eps = e->cfg.norm_eps;
-  {  // RMSNorm + QKV + RoPE + cache write
-    SmolttsGemmArgs a = base_gemm(A + bw.wqkv, x, dim, M, (n_head + 2 * n_kv) * 64, dim);
-    a.prologue = SMOLTTS_PRO_RMSNORM; a.epilogue = SMOLTTS_EPI_QKV_ROPE;
-    a.gamma_dev = (const float*)(A + bw.attn_norm); a.eps = eps;
-    a.out_dev = q; a.ldo = n_head * 64;
+  {  // RMSNorm scale + QKV + RoPE + cache write
+    SmolttsGemm3Args a = base3(A + bw.wqkv, in_x3, M, (n_head + 2 * n_kv) * 64, dim, SMOLTTS_EPI_QKV_ROPE);
+    a.ssq_in_dev = s->ssq; a.eps = eps; a.out_dev = q; a.ldo = n_head * 64;
     a.rope_dev = rope; a.row_pos_dev = row_pos; a.row_slot_dev = row_slot;
     a.k_cache_dev = kc; a.v_cache_dev = vc; a.n_q_heads = n_head; a.n_kv_heads = n_kv; a.cache_len = cache_len;
-    ST_TRY(launch_gemm(a, st));
+    ST_TRY(launch_gemm3(a, st));
   }
-  ST_TRY(launch_attention(q, kc, vc, row_pos, row_slot, M, n_head, n_kv, cache_len, 0, attn, st));
-  {  // x += attn . Wo^T
-    SmolttsGemmArgs a = base_gemm(A + bw.wo, attn, dim, M, dim, dim);
-    a.epilogue = SMOLTTS_EPI_RESID; a.resid_dev = x; a.out_dev = x; a.ldo = dim;
-    ST_TRY(launch_gemm(a, st));
+  ST_TRY(launch_attention(q, kc, vc, row_pos, row_slot, M, n_head, n_kv, cache_len, 0, nullptr, s->x3a, st));
+  {  // x += attn . Wo^T ; publish x * ffn_norm for w1|w3
+    SmolttsGemm3Args a = base3(A + bw.wo, s->x3a, M, dim, dim, SMOLTTS_EPI_RESID);
+    a.resid_dev = x; a.out_dev = x; a.ldo = dim;
+    a.emit_a_dev = s->x3n; a.gamma_a_dev = (const float*)(A + bw.ffn_norm); a.ssq_out_dev = s->ssq;
+    ST_TRY(launch_gemm3(a, st));
   }
-  {  // h = silu(w1 n) * (w3 n), n = RMSNorm(x)
-    SmolttsGemmArgs a = base_gemm(A + bw.w13, x, dim, M, 2 * inter, dim);
-    a.prologue = SMOLTTS_PRO_RMSNORM; a.epilogue = SMOLTTS_EPI_SWIGLU;
-    a.gamma_dev = (const float*)(A + bw.ffn_norm); a.eps = eps;
-    a.out_dev = h; a.ldo = inter;
-    ST_TRY(launch_gemm(a, st));
+  {  // h = silu(w1 n) * (w3 n), n = RMSNorm(x); written as w2's operand
+    SmolttsGemm3Args a = base3(A + bw.w13, s->x3n, M, 2 * inter, dim, SMOLTTS_EPI_SWIGLU);
+    a.ssq_in_dev = s->ssq; a.eps = eps; a.x3_out_dev = s->x3h;
+    ST_TRY(launch_gemm3(a, st));
   }
-  {  // x += h . W2^T
-    SmolttsGemmArgs a = base_gemm(A + bw.w2, h, inter, M, dim, inter);
-    a.epilogue = SMOLTTS_EPI_RESID; a.resid_dev = x; a.out_dev = x; a.ldo = dim;
-    ST_TRY(launch_gemm(a, st));
+  {  // x += h . W2^T ; publish for the next consumer(s)
+    SmolttsGemm3Args a = base3(A + bw.w2, s->x3h, M, dim, inter, SMOLTTS_EPI_RESID);
+    a.resid_dev = x; a.out_dev = x; a.ldo = dim;
+    a.emit_a_dev = next.x3a; a.gamma_a_dev = next.gamma_a; a.emit_b_dev = next.x3b; a.gamma_b_dev = next.gamma_b;
+    a.ssq_out_dev = next.ssq;
+    ST_TRY(launch_gemm3(a, st));
   }
   return SMOLTTS_OK;
 }
 
+const float* gamma_at(const SmolttsEngine* e, uint64_t off) { return (const float*)(e->arena + off); }
+
+// What the producer of the slow hidden state publishes: head operand (x * norm) and the depth
+// transformer's first operand (x * fast_layers[0].attention_norm, or raw x for fast_project_in).
+EmitArgs slow_hidden_emit(const SmolttsSession* s) {
+  const SmolttsEngine* e = s->e;
+  EmitArgs em{s->x3n, gamma_at(e, e->w.norm), s->x3n2,
+              e->cfg.has_fast_project_in ? nullptr : gamma_at(e, e->w.fast_layers[0].attn_norm), s->ssq};
+  return em;
+}
+
+// xt[slots[i]] = xr[last_row[i]]
+__global__ __launch_bounds__(256) void scatter_last_kernel(const float* xr, const int* slots, const int* last_row, int dim,
+                                                           float* xt) {
+  const int i = blockIdx.x;
+  const long src = last_row[i], dst = slots[i];
+  for (int d = threadIdx.x * 4; d < dim; d += 256 * 4)
+    *reinterpret_cast<float4*>(xt + dst * dim + d) = *reinterpret_cast<const float4*>(xr + src * dim + d);
+}
+
 // Slow head + the depth transformer for all B slots; columns land in new_col, commit applies `mask`.
+// Precondition: xt holds the pre-norm slow hidden and has been published via slow_hidden_emit().
 int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
   const SmolttsEngine* e = s->e;
   const SmolttsLMConfig& c = e->cfg;
   const char* A = e->arena;
   const int B = s->B, H = 1 + c.n_fast;
   {  // logits = RMSNorm(x) . E^T   (lm/rq_transformer.py:184-189)
-    SmolttsGemmArgs a = base_gemm(A + e->w.head, s->xt, c.dim, B, c.vocab_size, c.dim);
-    a.prologue = SMOLTTS_PRO_RMSNORM; a.epilogue = SMOLTTS_EPI_STORE;
-    a.gamma_dev = (const float*)(A + e->w.norm); a.eps = c.norm_eps;
-    a.out_dev = s->logits; a.ldo = c.vocab_size;
-    ST_TRY(launch_gemm(a, st));
+    SmolttsGemm3Args a = base3(A + e->w.head, s->x3n, B, c.vocab_size, c.dim, SMOLTTS_EPI_STORE);
+    a.ssq_in_dev = s->ssq; a.eps = c.norm_eps; a.out_dev = s->logits; a.ldo = c.vocab_size;
+    ST_TRY(launch_gemm3(a, st));
   }
-  ST_TRY(launch_argmax(s->logits, B, c.vocab_size, c.vocab_size, s->new_col, H, s->margin, s->mask, nullptr, 0, 0, nullptr, st));
+  ST_TRY(launch_argmax(s->logits, B, c.vocab_size, c.vocab_size, s->new_col, H, s->margin, s->mask, nullptr, 0, 0, nullptr,
+                       nullptr, st));
   float* xf = s->xt;  // fast input = pre-norm slow hidden (lm/rq_transformer.py:191)
-  if (c.has_fast_project_in) {
-    SmolttsGemmArgs a = base_gemm(A + e->w.fast_proj_w, s->xt, c.dim, B, c.fast_dim, c.dim);
-    a.epilogue = SMOLTTS_EPI_STORE; a.bias_dev = (const float*)(A + e->w.fast_proj_b);
-    a.out_dev = s->xf; a.ldo = c.fast_dim;
-    ST_TRY(launch_gemm(a, st));
+  const char* first_x3 = s->x3n2;
+  const EmitArgs to_fast0{s->x3n, gamma_at(e, e->w.fast_layers[0].attn_norm), nullptr, nullptr, s->ssq};
+  if (c.has_fast_project_in) {  // Linear(dim, fast_dim) with bias (modeling :339-342)
+    SmolttsGemm3Args a = base3(A + e->w.fast_proj_w, s->x3n2, B, c.fast_dim, c.dim, SMOLTTS_EPI_STORE);
+    a.bias_dev = (const float*)(A + e->w.fast_proj_b); a.out_dev = s->xf; a.ldo = c.fast_dim;
+    a.emit_a_dev = to_fast0.x3a; a.gamma_a_dev = to_fast0.gamma_a; a.ssq_out_dev = s->ssq;
+    ST_TRY(launch_gemm3(a, st));
     xf = s->xf;
+    first_x3 = s->x3n;
   }
   const size_t fl_stride = (size_t)B * c.fast_n_kv_head * c.n_fast * 64;
   for (int i = 0; i < c.n_fast; ++i) {
-    for (int l = 0; l < c.n_fast_layer; ++l)
-      ST_TRY(run_block(e, e->w.fast_layers[l], c.fast_dim, c.fast_n_head, c.fast_n_kv_head, c.fast_inter, xf, s->qt, s->at,
-                       s->ht, B, s->fastpos + (size_t)i * B, s->iota, (const float*)(A + e->w.fast_rope),
-                       s->fkc + l * fl_stride, s->fvc + l * fl_stride, c.n_fast, st));
+    for (int l = 0; l < c.n_fast_layer; ++l) {
+      const EmitArgs next{s->x3n,
+                          gamma_at(e, l + 1 < c.n_fast_layer ? e->w.fast_layers[l + 1].attn_norm : e->w.fast_norm),
+                          nullptr, nullptr, s->ssq};
+      ST_TRY(run_block(s, e->w.fast_layers[l], c.fast_dim, c.fast_n_head, c.fast_n_kv_head, c.fast_inter, xf, s->qt, B,
+                       s->fastpos + (size_t)i * B, s->iota, (const float*)(A + e->w.fast_rope), s->fkc + l * fl_stride,
+                       s->fvc + l * fl_stride, c.n_fast, (i == 0 && l == 0) ? first_x3 : s->x3n, next, st));
+    }
     {  // fast_norm + depthwise head slice i  (lm/rq_transformer.py:209-217)
       const size_t wrow = (size_t)i * e->w.fast_head_step_stride;  // rows; a row tile is 16 rows
-      SmolttsGemmArgs a = base_gemm(A + e->w.fast_head + wrow * c.fast_dim * 2, xf, c.fast_dim, B, c.codebook_size, c.fast_dim);
-      a.prologue = SMOLTTS_PRO_RMSNORM; a.epilogue = SMOLTTS_EPI_STORE;
-      a.gamma_dev = (const float*)(A + e->w.fast_norm); a.eps = c.norm_eps;
-      a.out_dev = s->logits; a.ldo = c.codebook_size;
-      ST_TRY(launch_gemm(a, st));
+      SmolttsGemm3Args a = base3(A + e->w.fast_head + wrow * c.fast_dim * 2, s->x3n, B, c.codebook_size, c.fast_dim, SMOLTTS_EPI_STORE);
+      a.ssq_in_dev = s->ssq; a.eps = c.norm_eps; a.out_dev = s->logits; a.ldo = c.codebook_size;
+      ST_TRY(launch_gemm3(a, st));
     }
     const bool more = i + 1 < c.n_fast;
     const int off = c.depthwise_wte ? (c.duplicate_code_0 ? i : i + 1) * c.codebook_size : 0;  // generate.py:136-140
-    // from step 1 on the fast input lives in xf's own buffer (never clobber the slow hidden twice)
     float* xnext = c.has_fast_project_in ? s->xf : s->xt;
     ST_TRY(launch_argmax(s->logits, B, c.codebook_size, c.codebook_size, s->new_col + 1 + i, H, s->margin, s->mask,
-                         more ? (const void*)(A + e->w.fast_emb) : nullptr, off, c.fast_dim, more ? xnext : nullptr, st));
+                         more ? (const void*)(A + e->w.fast_emb) : nullptr, off, c.fast_dim, more ? xnext : nullptr,
+                         more ? &to_fast0 : nullptr, st));
     xf = xnext;
   }
   hipLaunchKernelGGL(commit_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, H, s->max_frames, c.im_end_id, s->stop_on_eos,
@@ -254,21 +281,39 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
   return SMOLTTS_OK;
 }
 
-int run_decode_frame(SmolttsSession* s, hipStream_t st) {
+// Slow transformer over M rows of x (already embedded and published for layer 0).
+int run_slow_layers(SmolttsSession* s, float* x, float* q, int M, const int* row_pos, const int* row_slot, bool publish_hidden,
+                    hipStream_t st) {
+  const SmolttsEngine* e = s->e;
+  const SmolttsLMConfig& c = e->cfg;
+  const size_t l_stride = (size_t)s->B * c.n_kv_head * s->max_seq * 64;
+  for (int l = 0; l < c.n_layer; ++l) {
+    EmitArgs next{nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (l + 1 < c.n_layer) next = EmitArgs{s->x3n, gamma_at(e, e->w.layers[l + 1].attn_norm), nullptr, nullptr, s->ssq};
+    else if (publish_hidden) next = slow_hidden_emit(s);
+    ST_TRY(run_block(s, e->w.layers[l], c.dim, c.n_head, c.n_kv_head, c.inter, x, q, M, row_pos, row_slot,
+                     (const float*)(e->arena + e->w.rope), s->kc + l * l_stride, s->vc + l * l_stride, s->max_seq, s->x3n, next, st));
+  }
+  return SMOLTTS_OK;
+}
+
+int embed_rows(SmolttsSession* s, const int* cols, int M, float* x, hipStream_t st) {
   const SmolttsEngine* e = s->e;
   const SmolttsLMConfig& c = e->cfg;
   const char* A = e->arena;
+  const int cb_first = c.duplicate_code_0 ? 0 : c.codebook_size;
+  const EmitArgs em{s->x3n, gamma_at(e, e->w.layers[0].attn_norm), nullptr, nullptr, s->ssq};
+  return launch_embed(cols, M, c.n_fast, A + e->w.text_emb, A + e->w.codebook_emb, c.dim, c.codebook_size, cb_first,
+                      c.embed_mask_mode, c.semantic_start_id, c.semantic_end_id, c.vocab_size, c.codebook_size * c.num_codebooks,
+                      x, &em, st);
+}
+
+int run_decode_frame(SmolttsSession* s, hipStream_t st) {
   const int B = s->B;
   hipLaunchKernelGGL(decode_mask_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, s->done, s->mask);
   ST_CHECK_HIP(hipGetLastError());
-  const int cb_first = c.duplicate_code_0 ? 0 : c.codebook_size;
-  ST_TRY(launch_embed(s->cur_col, B, c.n_fast, A + e->w.text_emb, A + e->w.codebook_emb, c.dim, c.codebook_size, cb_first,
-                      c.embed_mask_mode, c.semantic_start_id, c.semantic_end_id, c.vocab_size,
-                      c.codebook_size * c.num_codebooks, s->xt, st));
-  const size_t l_stride = (size_t)B * c.n_kv_head * s->max_seq * 64;
-  for (int l = 0; l < c.n_layer; ++l)
-    ST_TRY(run_block(e, e->w.layers[l], c.dim, c.n_head, c.n_kv_head, c.inter, s->xt, s->qt, s->at, s->ht, B, s->pos, s->iota,
-                     (const float*)(A + e->w.rope), s->kc + l * l_stride, s->vc + l * l_stride, s->max_seq, st));
+  ST_TRY(embed_rows(s, s->cur_col, B, s->xt, st));
+  ST_TRY(run_slow_layers(s, s->xt, s->qt, B, s->pos, s->iota, /*publish_hidden=*/true, st));
   return run_tail(s, /*advance_pos=*/1, st);
 }
 
@@ -395,7 +440,6 @@ int smoltts_lm_prefill(SmolttsSession* s, const int32_t* grid_dev, const int32_t
   hipStream_t st = (hipStream_t)stream;
   const SmolttsEngine* e = s->e;
   const SmolttsLMConfig& c = e->cfg;
-  const char* A = e->arena;
   if (s->stop_on_eos != stop_on_eos && s->graph_ready) {  // the flag is baked into the captured commit node
     (void)hipGraphExecDestroy(s->graph_exec);
     s->graph_ready = false;
@@ -409,16 +453,14 @@ int smoltts_lm_prefill(SmolttsSession* s, const int32_t* grid_dev, const int32_t
   hipLaunchKernelGGL(slot_reset_kernel, dim3((s->B + 63) / 64), dim3(64), 0, st, s->B, n_slots, s->stage_slots, s->stage_last,
                      row_pos_dev, s->pos, s->frames, s->done, s->mask, s->margin);
   ST_CHECK_HIP(hipGetLastError());
-  const int cb_first = c.duplicate_code_0 ? 0 : c.codebook_size;
-  ST_TRY(launch_embed(grid_dev, n_rows, c.n_fast, A + e->w.text_emb, A + e->w.codebook_emb, c.dim, c.codebook_size, cb_first,
-                      c.embed_mask_mode, c.semantic_start_id, c.semantic_end_id, c.vocab_size,
-                      c.codebook_size * c.num_codebooks, s->xr, st));
-  const size_t l_stride = (size_t)s->B * c.n_kv_head * s->max_seq * 64;
-  for (int l = 0; l < c.n_layer; ++l)
-    ST_TRY(run_block(e, e->w.layers[l], c.dim, c.n_head, c.n_kv_head, c.inter, s->xr, s->qr, s->ar, s->hr, n_rows, row_pos_dev,
-                     row_slot_dev, (const float*)(A + e->w.rope), s->kc + l * l_stride, s->vc + l * l_stride, s->max_seq, st));
+  ST_TRY(embed_rows(s, grid_dev, n_rows, s->xr, st));
+  ST_TRY(run_slow_layers(s, s->xr, s->qr, n_rows, row_pos_dev, row_slot_dev, /*publish_hidden=*/false, st));
   hipLaunchKernelGGL(scatter_last_kernel, dim3(n_slots), dim3(256), 0, st, s->xr, s->stage_slots, s->stage_last, c.dim, s->xt);
   ST_CHECK_HIP(hipGetLastError());
+  {  // publish the slow hidden rows of all B slots (rows of slots not being started are masked at commit)
+    const EmitArgs em = slow_hidden_emit(s);
+    ST_TRY(launch_x3_pack(s->xt, c.dim, s->B, c.dim, em.x3a, em.gamma_a, em.x3b, em.gamma_b, em.ssq, st));
+  }
   ST_TRY(run_tail(s, /*advance_pos=*/0, st));
   s->prefilled = true;
   return SMOLTTS_OK;

@@ -270,7 +270,7 @@ int smoltts_mimi_decode_chunk(SmolttsMimiSession* s, const int32_t* codes_dev, i
       ST_TRY(launch_gemm(a, st));
     }
     ST_TRY(launch_attention(s->tq, s->kc + l * l_stride, s->vc + l * l_stride, s->row_pos, s->row_slot, R, HEADS, HEADS,
-                            c.max_positions, c.window, s->ta, st));
+                            c.max_positions, c.window, s->ta, nullptr, st));
     {
       SmolttsGemmArgs a = gemm_f32(A + lw.wo, s->ta, D, R, D, D);
       a.epilogue = SMOLTTS_EPI_SCALE_RESID; a.scale_dev = (const float*)(A + lw.ls1);

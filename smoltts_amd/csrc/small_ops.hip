@@ -1,7 +1,7 @@
 // Gather / reduce operators around the GEMMs: token embedding, greedy argmax (+ next-step
 // embedding gather), LayerNorm, row gather.  All are HBM/L2-bound byte movers: one workgroup per
 // row, 16-byte (fp32) / 8-byte (bf16x4) accesses per lane, fixed-order reductions.
-#include "common.h"
+#include "x3.h"
 
 namespace smoltts {
 
@@ -12,7 +12,9 @@ namespace smoltts {
 __global__ __launch_bounds__(256) void embed_kernel(const int* cols, int n_code_rows, const uint16_t* text_emb,
                                                     const uint16_t* cb_emb, int dim, int codebook_size,
                                                     int cb_first_offset, int mask_mode, int sem_start, int sem_end,
-                                                    int text_rows, int cb_rows, float* x) {
+                                                    int text_rows, int cb_rows, float* x, EmitDev emit) {
+  __shared__ float sh4[4];
+  float ss = 0.f;
   const int r = blockIdx.x;
   const int* c = cols + (long)r * (1 + n_code_rows);
   int tok = c[0];
@@ -29,18 +31,24 @@ __global__ __launch_bounds__(256) void embed_kernel(const int* cols, int n_code_
         acc.x += bf16_lo(e.x); acc.y += bf16_hi(e.x); acc.z += bf16_lo(e.y); acc.w += bf16_hi(e.y);
       }
     }
-    *reinterpret_cast<float4*>(x + (long)r * dim + d) =
-        make_float4(bf16_lo(t.x) + acc.x, bf16_hi(t.x) + acc.y, bf16_lo(t.y) + acc.z, bf16_hi(t.y) + acc.w);
+    const float4 o = make_float4(bf16_lo(t.x) + acc.x, bf16_hi(t.x) + acc.y, bf16_lo(t.y) + acc.z, bf16_hi(t.y) + acc.w);
+    *reinterpret_cast<float4*>(x + (long)r * dim + d) = o;
+    ss += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+    emit_x4(emit, r, d, dim >> 5, o.x, o.y, o.z, o.w);
   }
+  emit_row_ssq(emit, r, dim, ss, sh4);
 }
 
 int launch_embed(const int32_t* cols, int n_rows, int n_code_rows, const void* text_emb, const void* cb_emb, int dim,
                  int codebook_size, int cb_first_offset, int mask_mode, int sem_start, int sem_end, int text_rows,
-                 int cb_rows, float* x, hipStream_t stream) {
+                 int cb_rows, float* x, const EmitArgs* emit, hipStream_t stream) {
+  EmitDev e{nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (emit) e = EmitDev{(char*)emit->x3a, emit->gamma_a, (char*)emit->x3b, emit->gamma_b, emit->ssq};
+  ST_REQUIRE(emit == nullptr || dim % 64 == 0, SMOLTTS_E_INVALID, "embed: X3 emission needs dim %% 64 == 0");
   ST_REQUIRE(cols && text_emb && cb_emb && x && n_rows > 0 && dim % 4 == 0 && n_code_rows >= 1, SMOLTTS_E_INVALID,
              "embed: bad arguments");
   hipLaunchKernelGGL(embed_kernel, dim3(n_rows), dim3(256), 0, stream, cols, n_code_rows, (const uint16_t*)text_emb,
-                     (const uint16_t*)cb_emb, dim, codebook_size, cb_first_offset, mask_mode, sem_start, sem_end, text_rows, cb_rows, x);
+                     (const uint16_t*)cb_emb, dim, codebook_size, cb_first_offset, mask_mode, sem_start, sem_end, text_rows, cb_rows, x, e);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
 }
@@ -67,8 +75,9 @@ __device__ __forceinline__ Top2 top2_merge(Top2 a, Top2 b) {
 
 __global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int n_cols, long ld, int* ids, int ids_stride,
                                                      float* margin, const int* margin_mask, const uint16_t* emb,
-                                                     int emb_row_offset, int dim, float* xnext) {
+                                                     int emb_row_offset, int dim, float* xnext, EmitDev emit) {
   __shared__ Top2 sh[4];
+  __shared__ float sh4[4];
   __shared__ int s_id;
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* row = logits + (long)r * ld;
@@ -99,19 +108,26 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int n_
   if (emb == nullptr) return;
   __syncthreads();
   const long erow = (long)s_id + emb_row_offset;
+  float ss = 0.f;
   for (int d = tid * 4; d < dim; d += 256 * 4) {
     const uint2 e = *reinterpret_cast<const uint2*>(emb + erow * dim + d);
-    *reinterpret_cast<float4*>(xnext + (long)r * dim + d) = make_float4(bf16_lo(e.x), bf16_hi(e.x), bf16_lo(e.y), bf16_hi(e.y));
+    const float4 o = make_float4(bf16_lo(e.x), bf16_hi(e.x), bf16_lo(e.y), bf16_hi(e.y));
+    *reinterpret_cast<float4*>(xnext + (long)r * dim + d) = o;
+    ss += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+    emit_x4(emit, r, d, dim >> 5, o.x, o.y, o.z, o.w);
   }
+  emit_row_ssq(emit, r, dim, ss, sh4);
 }
 
 int launch_argmax(const float* logits, int n_rows, int n_cols, int64_t ld, int32_t* ids, int ids_stride, float* margin,
                   const int32_t* margin_mask, const void* emb, int emb_row_offset, int dim, float* xnext,
-                  hipStream_t stream) {
+                  const EmitArgs* emit, hipStream_t stream) {
+  EmitDev e{nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (emit && emb) e = EmitDev{(char*)emit->x3a, emit->gamma_a, (char*)emit->x3b, emit->gamma_b, emit->ssq};
   ST_REQUIRE(logits && ids && n_rows > 0 && n_cols > 0, SMOLTTS_E_INVALID, "argmax: bad arguments");
   ST_REQUIRE(emb == nullptr || (xnext && dim % 4 == 0), SMOLTTS_E_INVALID, "argmax: bad gather arguments");
   hipLaunchKernelGGL(argmax_kernel, dim3(n_rows), dim3(256), 0, stream, logits, n_cols, (long)ld, ids, ids_stride, margin,
-                     margin_mask, (const uint16_t*)emb, emb_row_offset, dim, xnext);
+                     margin_mask, (const uint16_t*)emb, emb_row_offset, dim, xnext, e);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
 }

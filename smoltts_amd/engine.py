@@ -85,7 +85,7 @@ _EXPORTS = [
     "smoltts_lm_decode", "smoltts_session_outputs", "smoltts_mimi_create", "smoltts_mimi_destroy",
     "smoltts_mimi_slab_bytes", "smoltts_mimi_session_create", "smoltts_mimi_session_destroy", "smoltts_mimi_reset",
     "smoltts_mimi_decode_chunk", "smoltts_k_gemm", "smoltts_k_attention", "smoltts_k_embed", "smoltts_k_argmax",
-    "smoltts_k_layernorm", "smoltts_profile_begin", "smoltts_profile_end",
+    "smoltts_k_layernorm", "smoltts_profile_begin", "smoltts_profile_end", "smoltts_k_gemm3", "smoltts_k_x3_pack",
 ]
 
 
@@ -127,7 +127,7 @@ def load_library(path: Optional[Path] = None):
     lib.smoltts_mimi_reset.argtypes = [C.c_void_p, C.c_void_p]
     lib.smoltts_mimi_decode_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
     lib.smoltts_k_gemm.argtypes = [C.POINTER(GemmArgs), C.c_void_p]
-    lib.smoltts_k_attention.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p, C.c_void_p]
+    lib.smoltts_k_attention.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.smoltts_k_embed.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]
     lib.smoltts_k_argmax.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.smoltts_k_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]

@@ -56,14 +56,14 @@ def linear(x: torch.Tensor, w_tiles: torch.Tensor, N: int, *, w_fp32: bool = Fal
 
 
 def attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, row_pos: torch.Tensor,
-              row_slot: torch.Tensor, n_q_heads: int, window: int = 0) -> torch.Tensor:
-    """q [rows, Hq*64]; caches [slots, KV, cache_len, 64]; -> [rows, Hq*64]."""
+              row_slot: torch.Tensor, n_q_heads: int, window: int = 0, out_x3: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q [rows, Hq*64]; caches [slots, KV, cache_len, 64]; -> [rows, Hq*64] (and the X3 operand if given)."""
     lib = E.load_library()
     n_kv, cache_len = k_cache.shape[1], k_cache.shape[2]
     out = torch.empty_like(q)
     E.check(lib.smoltts_k_attention(E.dptr(q), E.dptr(k_cache), E.dptr(v_cache), E.dptr(row_pos), E.dptr(row_slot),
-                                    q.shape[0], n_q_heads, n_kv, cache_len, window, E.dptr(out), E.current_stream_ptr()),
-            "smoltts_k_attention")
+                                    q.shape[0], n_q_heads, n_kv, cache_len, window, E.dptr(out), E.dptr(out_x3),
+                                    E.current_stream_ptr()), "smoltts_k_attention")
     return out
 
 
@@ -92,4 +92,75 @@ def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e
     out = torch.empty_like(x)
     E.check(lib.smoltts_k_layernorm(E.dptr(x), E.dptr(w), E.dptr(b), x.shape[0], x.shape[1], eps, E.dptr(out),
                                     E.current_stream_ptr()), "smoltts_k_layernorm")
+    return out
+
+
+# ------------------------------------------------------------------------------- X3 / bf16-MFMA path
+def x3_bytes(rows: int, K: int) -> int:
+    return (rows + 15) // 16 * 16 * K * 6
+
+
+def x3_alloc(rows: int, K: int) -> torch.Tensor:
+    return torch.zeros(x3_bytes(rows, K), dtype=torch.uint8, device="cuda")
+
+
+def x3_to_float(buf: torch.Tensor, rows: int, K: int) -> torch.Tensor:
+    """Decode an X3 operand buffer back to fp32 [rows, K] on the CPU (tests): hi + mid + lo."""
+    R16 = (rows + 15) // 16 * 16
+    t = buf.cpu()[: R16 * K * 6].view(torch.bfloat16).view(R16 // 16, K // 32, 3, 4, 16, 8)  # tile, chunk, piece, q, r, j
+    f = t.float().sum(dim=2)  # tile, chunk, q, r, j  (exact: the pieces do not overlap)
+    return f.permute(0, 3, 1, 2, 4).reshape(R16, K)[:rows].contiguous()
+
+
+def x3_pack(x: torch.Tensor, gamma_a: Optional[torch.Tensor] = None, gamma_b: Optional[torch.Tensor] = None,
+            two: bool = False):
+    """fp32 rows on the GPU -> (X3 of x*gamma_a, X3 of x*gamma_b or None, ssq [rows, K/16])."""
+    lib = E.load_library()
+    rows, K = x.shape
+    a = x3_alloc(rows, K)
+    b = x3_alloc(rows, K) if two else None
+    ssq = torch.zeros(rows, K // 16, dtype=torch.float32, device=x.device)
+    lib.smoltts_k_x3_pack.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 6
+    E.check(lib.smoltts_k_x3_pack(E.dptr(x), x.stride(0), rows, K, E.dptr(a), E.dptr(gamma_a), E.dptr(b), E.dptr(gamma_b),
+                                  E.dptr(ssq), E.current_stream_ptr()), "smoltts_k_x3_pack")
+    return a, b, ssq
+
+
+class Gemm3Args(C.Structure):
+    _fields_ = [
+        ("w_dev", C.c_void_p), ("x3_dev", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("epilogue", C.c_int32), ("ssq_in_dev", C.c_void_p), ("eps", C.c_float), ("bias_dev", C.c_void_p),
+        ("resid_dev", C.c_void_p), ("out_dev", C.c_void_p), ("ldo", C.c_int64), ("x3_out_dev", C.c_void_p),
+        ("emit_a_dev", C.c_void_p), ("gamma_a_dev", C.c_void_p), ("emit_b_dev", C.c_void_p), ("gamma_b_dev", C.c_void_p),
+        ("ssq_out_dev", C.c_void_p), ("rope_dev", C.c_void_p), ("row_pos_dev", C.c_void_p), ("row_slot_dev", C.c_void_p),
+        ("k_cache_dev", C.c_void_p), ("v_cache_dev", C.c_void_p), ("n_q_heads", C.c_int32), ("n_kv_heads", C.c_int32),
+        ("cache_len", C.c_int32),
+    ]
+
+
+def linear3(x3: torch.Tensor, w_tiles: torch.Tensor, M: int, N: int, K: int, *, epilogue: int = E.EPI_STORE,
+            ssq_in: Optional[torch.Tensor] = None, eps: float = 1e-5, bias: Optional[torch.Tensor] = None,
+            resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, x3_out: Optional[torch.Tensor] = None,
+            emit_a: Optional[torch.Tensor] = None, gamma_a: Optional[torch.Tensor] = None,
+            emit_b: Optional[torch.Tensor] = None, gamma_b: Optional[torch.Tensor] = None,
+            ssq_out: Optional[torch.Tensor] = None, rope=None, row_pos=None, row_slot=None, k_cache=None, v_cache=None,
+            n_q_heads: int = 0, n_kv_heads: int = 0, cache_len: int = 0):
+    """The bf16-MFMA GEMM over an X3 operand; returns the fp32 ``out`` tensor (None for SWIGLU)."""
+    lib = E.load_library()
+    lib.smoltts_k_gemm3.argtypes = [C.POINTER(Gemm3Args), C.c_void_p]
+    if out is None and epilogue != E.EPI_SWIGLU:
+        cols = n_q_heads * 64 if epilogue == E.EPI_QKV_ROPE else N
+        out = torch.zeros(M, cols, dtype=torch.float32, device=x3.device)
+    a = Gemm3Args()
+    a.w_dev, a.x3_dev, a.M, a.N, a.K, a.epilogue = E.dptr(w_tiles), E.dptr(x3), M, N, K, epilogue
+    a.ssq_in_dev, a.eps, a.bias_dev, a.resid_dev = E.dptr(ssq_in), eps, E.dptr(bias), E.dptr(resid)
+    a.out_dev = E.dptr(out)
+    a.ldo = out.stride(0) if out is not None else 0
+    a.x3_out_dev = E.dptr(x3_out)
+    a.emit_a_dev, a.gamma_a_dev, a.emit_b_dev, a.gamma_b_dev = E.dptr(emit_a), E.dptr(gamma_a), E.dptr(emit_b), E.dptr(gamma_b)
+    a.ssq_out_dev = E.dptr(ssq_out)
+    a.rope_dev, a.row_pos_dev, a.row_slot_dev = E.dptr(rope), E.dptr(row_pos), E.dptr(row_slot)
+    a.k_cache_dev, a.v_cache_dev = E.dptr(k_cache), E.dptr(v_cache)
+    a.n_q_heads, a.n_kv_heads, a.cache_len = n_q_heads, n_kv_heads, cache_len
+    E.check(lib.smoltts_k_gemm3(C.byref(a), E.current_stream_ptr()), "smoltts_k_gemm3")
     return out
