@@ -295,6 +295,12 @@ int smoltts_k_x3_pack(const float* x_dev, int64_t ldx, int32_t n_rows, int32_t d
  * being captured.  profile_end synchronises the events and returns the summed kernel time. */
 int smoltts_profile_begin(int32_t prologue, int32_t epilogue, int32_t n_filter, int32_t max_launches);
 int smoltts_profile_end(float* total_ms, int32_t* n_launches);
+/* Measurement aid for graph replays: while set (epilogue >= 0), every bf16 GEMM launch with that
+ * epilogue (and N == n_filter when n_filter > 0; EPI_RESID excluded: not idempotent) is issued twice.
+ * Capture a frame graph with and without it: the time difference per extra launch is the kernel's
+ * in-situ duration.  smoltts_session_drop_graph makes the next smoltts_lm_decode re-capture. */
+int smoltts_debug_duplicate(int32_t epilogue, int32_t n_filter);
+int smoltts_session_drop_graph(SmolttsSession* s);
 
 /* GQA attention of one query row per (row, kv head) over the slot's cache prefix:
  * keys [max(0, pos+1-window), pos]; q_dev/out_dev [n_rows][n_q_heads*64]; out_x3_dev (optional) receives

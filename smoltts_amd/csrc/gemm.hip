@@ -291,6 +291,8 @@ struct ProfileState {
 static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream);
 static unsigned long long* g_stamps = nullptr;
 
+unsigned long long* debug_stamp_buffer() { return g_stamps; }
+
 // shared with gemm3.hip: returns the event-pair index to close with profile_hook_end, or -1
 int profile_hook_begin(int prologue, int epilogue, int N, hipStream_t stream) {
   const bool hit = g_prof.on && prologue == g_prof.pro && epilogue == g_prof.epi && (g_prof.n <= 0 || N == g_prof.n) &&

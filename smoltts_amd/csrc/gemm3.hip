@@ -44,7 +44,16 @@ struct Gemm3Dev {
   float* kc;
   float* vc;
   int n_q_heads, n_kv_heads, cache_len;
+  unsigned long long* stamps;  // diagnostics only (smoltts_debug_set_stamps); nullptr in production
 };
+
+#define STAMP3(k)                                                                             \
+  do {                                                                                        \
+    if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {                        \
+      p.stamps[(wave * 8 + (k)) * 2] = clock64();                                             \
+      p.stamps[(wave * 8 + (k)) * 2 + 1] = wall_clock64();                                    \
+    }                                                                                         \
+  } while (0)
 
 __device__ __forceinline__ float silu3(float x) { return x / (1.f + expf(-x)); }
 
@@ -59,6 +68,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
   constexpr bool kResid = EPI == SMOLTTS_EPI_RESID;
   constexpr bool kEmits = EPI == SMOLTTS_EPI_RESID || EPI == SMOLTTS_EPI_STORE;
   constexpr bool kRope = EPI == SMOLTTS_EPI_QKV_ROPE;
+  STAMP3(0);
 
   // ---- epilogue inputs of the waves that will finish the tiles (waves < MT): every load is issued
   //      here, ahead of the operand stream, so that the tail of the kernel waits on nothing
@@ -143,6 +153,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
     }
   }
 
+  STAMP3(1);
   // RoPE rows of the finishing waves (needs pos, which arrived long ago); in flight across the barrier
   float4 cs[T];
   if (kRope && fin) {
@@ -162,7 +173,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
     for (int mt = 0; mt < MT; ++mt)
       red4[((wave * T + t) * MT + mt) * 64 + lane] = make_float4(acc[t][mt][0], acc[t][mt][1], acc[t][mt][2], acc[t][mt][3]);
   }
+  STAMP3(2);
   __syncthreads();
+  STAMP3(3);
   if (!fin) return;
   const int mt = wave;  // lane, r, q keep their meaning
 
@@ -234,6 +247,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
       }
     }
   }
+  STAMP3(4);
 }
 
 template <int MT, int T, int U, int EPI>
@@ -268,15 +282,23 @@ static int launch3_epi(const Gemm3Dev& d, hipStream_t stream) {
   return launch3_one<1, 1, 3, EPI>(d, nwaves, stream);
 }
 
+unsigned long long* debug_stamp_buffer();  // gemm.hip
 int profile_hook_begin(int prologue, int epilogue, int N, hipStream_t stream);  // gemm.hip
 void profile_hook_end(int i, hipStream_t stream);
 static int launch_gemm3_impl(const SmolttsGemm3Args& a, hipStream_t stream);
 
+// Measurement aid (smoltts_debug_duplicate): launches matching the filter are issued twice.  The
+// second launch recomputes the same outputs, so a frame graph captured with the filter on costs
+// exactly n extra launches of that kernel in situ: (t_dup - t_base) / n is its per-launch time.
+static int g_dup_epi = -1, g_dup_n = 0;
+
 int launch_gemm3(const SmolttsGemm3Args& a, hipStream_t stream) {
-  // the measurement hook sees a normed input as the RMSNorm prologue
+  // the event hook sees a normed input as the RMSNorm prologue
   const int i = profile_hook_begin(a.ssq_in_dev ? SMOLTTS_PRO_RMSNORM : SMOLTTS_PRO_NONE, a.epilogue, a.N, stream);
-  const int rc = launch_gemm3_impl(a, stream);
+  int rc = launch_gemm3_impl(a, stream);
   profile_hook_end(i, stream);
+  if (rc == SMOLTTS_OK && g_dup_epi == a.epilogue && (g_dup_n <= 0 || g_dup_n == a.N) && a.epilogue != SMOLTTS_EPI_RESID)
+    rc = launch_gemm3_impl(a, stream);
   return rc;
 }
 
@@ -294,6 +316,7 @@ static int launch_gemm3_impl(const SmolttsGemm3Args& a, hipStream_t stream) {
   d.emit.gamma_b = a.gamma_b_dev; d.emit.ssq = a.ssq_out_dev;
   d.rope = a.rope_dev; d.row_pos = a.row_pos_dev; d.row_slot = a.row_slot_dev; d.kc = a.k_cache_dev; d.vc = a.v_cache_dev;
   d.n_q_heads = a.n_q_heads; d.n_kv_heads = a.n_kv_heads; d.cache_len = a.cache_len;
+  d.stamps = debug_stamp_buffer();
   switch (a.epilogue) {
     case SMOLTTS_EPI_STORE:
       ST_REQUIRE(a.out_dev && a.ldo % 4 == 0, SMOLTTS_E_INVALID, "gemm3: STORE needs out/ldo");
@@ -342,6 +365,11 @@ int launch_x3_pack(const float* x, int64_t ldx, int n_rows, int dim, void* x3a, 
 }  // namespace smoltts
 
 extern "C" {
+int smoltts_debug_duplicate(int32_t epilogue, int32_t n_filter) {
+  smoltts::g_dup_epi = epilogue;
+  smoltts::g_dup_n = n_filter;
+  return SMOLTTS_OK;
+}
 int smoltts_k_gemm3(const SmolttsGemm3Args* a, void* stream) {
   using namespace smoltts;
   ST_REQUIRE(a, SMOLTTS_E_INVALID, "k_gemm3: null args");

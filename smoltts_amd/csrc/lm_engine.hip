@@ -502,6 +502,16 @@ int smoltts_lm_decode(SmolttsSession* s, int32_t n_frames, void* stream) {
   return SMOLTTS_OK;
 }
 
+// Forget the captured frame graph (the next smoltts_lm_decode captures it again).
+int smoltts_session_drop_graph(SmolttsSession* s) {
+  ST_REQUIRE(s, SMOLTTS_E_INVALID, "session_drop_graph: null session");
+  if (s->graph_ready) {
+    (void)hipGraphExecDestroy(s->graph_exec);
+    s->graph_ready = false;
+  }
+  return SMOLTTS_OK;
+}
+
 int smoltts_session_outputs(SmolttsSession* s, int32_t** codes_dev, int32_t** n_frames_dev, int32_t** done_dev,
                             float** margin_dev) {
   ST_REQUIRE(s, SMOLTTS_E_INVALID, "session_outputs: null session");

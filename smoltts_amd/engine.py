@@ -86,6 +86,7 @@ _EXPORTS = [
     "smoltts_mimi_slab_bytes", "smoltts_mimi_session_create", "smoltts_mimi_session_destroy", "smoltts_mimi_reset",
     "smoltts_mimi_decode_chunk", "smoltts_k_gemm", "smoltts_k_attention", "smoltts_k_embed", "smoltts_k_argmax",
     "smoltts_k_layernorm", "smoltts_profile_begin", "smoltts_profile_end", "smoltts_k_gemm3", "smoltts_k_x3_pack",
+    "smoltts_debug_duplicate", "smoltts_session_drop_graph",
 ]
 
 
@@ -131,6 +132,8 @@ def load_library(path: Optional[Path] = None):
     lib.smoltts_k_embed.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]
     lib.smoltts_k_argmax.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.smoltts_k_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
+    lib.smoltts_debug_duplicate.argtypes = [C.c_int32, C.c_int32]
+    lib.smoltts_session_drop_graph.argtypes = [C.c_void_p]
     lib.smoltts_profile_begin.argtypes = [C.c_int32] * 4
     lib.smoltts_profile_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     if lib.smoltts_abi_version() != 1:

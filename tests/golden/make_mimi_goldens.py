@@ -1,0 +1,42 @@
+"""Generate the committed Mimi golden vectors (runs wherever `transformers` is installed).
+
+The Mimi arithmetic of the reference lives in third-party code: the MLX port under
+mlx_inference/src/smoltts_mlx/codec/ (not importable: no `mlx`) mirrors `transformers.MimiModel`
+(used by the reference's data_pipeline/utils/codec.py:4,19).  This script loads our seeded
+synthetic decoder-side weights into `transformers.MimiModel`, decodes seeded codes with it and
+stores (seed, codes, pcm) as data.  tests/test_mimi_oracle.py checks oracle/mimi_oracle.py against
+both the live third-party model and these vectors.
+
+Usage: python tests/golden/make_mimi_goldens.py
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+from smoltts_amd.codec.synthetic import synthetic_mimi_state  # noqa: E402
+
+
+def main():
+    from transformers import MimiConfig, MimiModel
+
+    seed, B, F = 3, 2, 6
+    st = synthetic_mimi_state(seed=seed)
+    m = MimiModel(MimiConfig()).eval()
+    res = m.load_state_dict(st, strict=False)
+    assert not res.unexpected_keys
+    g = torch.Generator().manual_seed(11)
+    codes = torch.randint(0, 2048, (B, 8, F), generator=g)
+    with torch.no_grad():
+        pcm = m.decode(codes)[0]
+    fp = float(sum(float(v.double().abs().sum()) for v in st.values()))
+    np.savez_compressed(Path(__file__).resolve().parent / "mimi_hf.npz", seed=seed, codes=codes.numpy().astype(np.int32),
+                        pcm=pcm.numpy().astype(np.float32), fingerprint=fp)
+    print("wrote mimi_hf.npz", pcm.shape, float(pcm.pow(2).mean().sqrt()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""CPU suite: the oracle against the committed golden vectors (which were produced against the
+reference's own RQTransformer.forward / against transformers.MimiModel), plus its self-consistency."""
+import numpy as np
+import pytest
+import torch
+
+
+def _lm(cfgname, seed):
+    from oracle.lm_oracle import LMOracle, OracleLMConfig
+    from smoltts_amd.synthetic import named_config, state_fingerprint, synthetic_lm_state
+
+    cfg = named_config(cfgname)
+    state = synthetic_lm_state(cfg, seed=seed)
+    return cfg, state, LMOracle(OracleLMConfig.from_dict(cfg.__dict__), state), state_fingerprint(state)
+
+
+@pytest.mark.parametrize("name", ["tiny", "70m"])
+def test_lm_oracle_reproduces_goldens(name, golden_dir):
+    g = np.load(golden_dir / f"lm_{name}.npz")
+    cfg, state, orc, fp = _lm(str(g["config_name"]), int(g["seed"]))
+    assert abs(fp - float(g["fingerprint"])) <= 1e-6 * abs(fp)
+    n = len(g["texts"])
+    logs = orc.generate([torch.from_numpy(g[f"prompt_{b}"]) for b in range(n)], max_frames=int(g["frames"]), stop_on_eos=False)
+    for b in range(n):
+        assert np.array_equal(logs[b].as_tensor().numpy(), g[f"grid_{b}"])
+        # the reference forward's own logits at three positions (teacher-forced on the golden grid)
+        full = torch.cat([torch.from_numpy(g[f"prompt_{b}"]).long(), torch.from_numpy(g[f"grid_{b}"]).long()], dim=1)
+        tok, cb = orc.teacher_forced(full)
+        rows = g[f"ref_rows_{b}"].tolist()
+        assert np.allclose(tok[rows].numpy(), g[f"ref_token_logits_{b}"], atol=5e-5)
+        assert np.allclose(cb[rows][:, :, :64].numpy(), g[f"ref_codebook_logits_{b}"], atol=2e-6)
+
+
+def test_lm_oracle_batch_invariance_and_eos():
+    """Batched decode == one-by-one decode; stop rule: the <|im_end|> frame is emitted, then nothing."""
+    from oracle.lm_oracle import LMOracle, OracleLMConfig
+    from smoltts_amd.prompt import PromptEncoder
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+    from smoltts_amd.tokenizer import load_tokenizer
+
+    cfg = named_config("tiny")
+    state = synthetic_lm_state(cfg, seed=5)
+    pe = PromptEncoder(load_tokenizer(), 320)
+    prompts = [torch.from_numpy(pe.build_prompt(t, "heart")) for t in ("abc", "a longer second prompt", "x")]
+    ocfg = OracleLMConfig.from_dict(cfg.__dict__)
+    batched = LMOracle(ocfg, state).generate(prompts, max_frames=6, stop_on_eos=False)
+    for b, p in enumerate(prompts):
+        single = LMOracle(ocfg, state).generate([p], max_frames=6, stop_on_eos=False)[0]
+        assert single.grid == batched[b].grid
+    eos = batched[1].grid[2][0]
+    ocfg2 = OracleLMConfig.from_dict({**cfg.__dict__, "im_end_id": eos})
+    logs = LMOracle(ocfg2, state).generate(prompts, max_frames=6, stop_on_eos=True)
+    first = next(f for f in range(6) if batched[1].grid[f][0] == eos)
+    assert len(logs[1].grid) == first + 1 and logs[1].grid == batched[1].grid[: first + 1]
+
+
+def test_lm_oracle_mlx_mode_differs_only_by_documented_quirks():
+    from oracle.lm_oracle import LMOracle, OracleLMConfig, rope_table
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+
+    cfg = named_config("tiny")
+    state = synthetic_lm_state(cfg, seed=1)
+    ocfg = OracleLMConfig.from_dict(cfg.__dict__)
+    a, b = LMOracle(ocfg, state, "torch", True), LMOracle(ocfg, state, "mlx", False)
+    cols = torch.tensor([[72] + [0] * 8, [320 + 5] + [5, 1, 2, 3, 4, 5, 6, 7], [400] + [0, 9, 9, 9, 9, 9, 9, 9]])
+    ea, eb = a.embed(cols), b.embed(cols)
+    assert torch.equal(ea[0], eb[0]) and torch.equal(ea[1], eb[1])  # text row / ordinary audio row agree
+    assert not torch.equal(ea[2], eb[2])  # code0 == 0 on a semantic row: torch zeroes the code sum, MLX keeps it
+    t_bf, t_ex = rope_table(64, 64, 1e5, True), rope_table(64, 64, 1e5, False)
+    assert float((t_bf - t_ex).abs().max()) < 4e-3 and not torch.equal(t_bf, t_ex)
+
+
+def test_mimi_oracle_matches_hf_goldens_and_live_model(golden_dir):
+    from oracle.mimi_oracle import MimiDecodeOracle
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+
+    g = np.load(golden_dir / "mimi_hf.npz")
+    st = synthetic_mimi_state(seed=int(g["seed"]))
+    fp = float(sum(float(v.double().abs().sum()) for v in st.values()))
+    assert abs(fp - float(g["fingerprint"])) <= 1e-9 * fp
+    codes = torch.from_numpy(g["codes"]).long()
+    out = MimiDecodeOracle(st, window=250).decode(codes).numpy()
+    assert out.shape == g["pcm"].shape
+    assert float(np.sqrt(np.mean((out - g["pcm"]) ** 2))) < 1e-6
+    # window = 0 (MLX behaviour) is identical while the context is shorter than 250 positions
+    assert np.array_equal(MimiDecodeOracle(st, window=0).decode(codes).numpy(), out)
+    transformers = pytest.importorskip("transformers")
+    m = transformers.MimiModel(transformers.MimiConfig()).eval()
+    m.load_state_dict(st, strict=False)
+    codes2 = torch.randint(0, 2048, (1, 8, 9), generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        ref = m.decode(codes2)[0].numpy()
+    assert float(np.sqrt(np.mean((MimiDecodeOracle(st, window=250).decode(codes2).numpy() - ref) ** 2))) < 1e-6
+
+
+def test_mimi_oracle_is_causal():
+    from oracle.mimi_oracle import MimiDecodeOracle
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+
+    orc = MimiDecodeOracle(synthetic_mimi_state(seed=1))
+    codes = torch.randint(0, 2048, (1, 8, 7), generator=torch.Generator().manual_seed(0))
+    full, prefix = orc.decode(codes), orc.decode(codes[:, :, :3])
+    assert float((full[..., : 3 * 1920] - prefix).abs().max()) < 1e-5
