@@ -1,2 +1,122 @@
-"""smoltts_amd: MI355X-native DualAR + Mimi decode hot path."""
+"""smoltts_amd: MI355X-native DualAR + Mimi decode hot path.
+
+``SmolTTS`` mirrors the reference façade mlx_inference/src/smoltts_mlx/__init__.py:25-151: same
+constructor arguments, ``__call__(input, voice) -> float32 PCM`` and ``stream(input, voice)`` yielding
+80 ms chunks (1920 samples at 24 kHz).  Everything heavy runs in ``libsmoltts_hip.so``.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Dict, Iterator, List, Optional
+
 __version__ = "0.1.0"
+
+
+class SmolTTS:
+    def __init__(self, model_id: Optional[str] = None, checkpoint_dir: Optional[str] = None,
+                 mimi_checkpoint: Optional[str] = None, numerics=None, state=None, config=None, mimi_state=None,
+                 codec_window: int = 0):
+        """``checkpoint_dir``: config.json + tokenizer.json + model.safetensors | model.pth (reference
+        layouts).  ``mimi_checkpoint``: the Hugging Face kyutai/mimi ``model.safetensors`` (or its
+        directory).  ``state``/``config``/``mimi_state`` allow in-memory (e.g. synthetic) weights.
+        ``model_id`` (Hugging Face download in the reference) needs network access and is refused."""
+        import torch  # noqa: F401
+
+        from .checkpoint import load_checkpoint, load_mimi_state
+        from .config import NumericsMode, TokenConfig
+        from .engine import LMEngine, MimiEngine
+        from .prompt import PromptEncoder
+        from .tokenizer import load_tokenizer
+
+        if checkpoint_dir is None and state is None:
+            raise ValueError("pass checkpoint_dir (or state+config); downloading model_id=%r needs network access" % (model_id,))
+        if checkpoint_dir is not None:
+            config, tokenizer, state = load_checkpoint(checkpoint_dir)
+        else:
+            tokenizer = load_tokenizer(None, config.codebook_size)
+        if mimi_state is None:
+            if mimi_checkpoint is None:
+                raise ValueError("pass mimi_checkpoint (kyutai/mimi model.safetensors) or mimi_state")
+            mimi_state = load_mimi_state(mimi_checkpoint)
+        self.config = config
+        self.tokenizer = tokenizer
+        self.token_config = TokenConfig.from_tokenizer(tokenizer, config)
+        self.lm = LMEngine(config, state, self.token_config, numerics or NumericsMode.torch_reference())
+        self.prompt_encoder = PromptEncoder.from_config(tokenizer, config, self.token_config)
+        self.codec = MimiEngine(mimi_state, num_codebooks=config.num_codebooks, window=codec_window, max_positions=2 * 1026 + 2)
+        self.sampling_rate = 24_000
+
+    # -- prompt (``_get_prompt``, __init__.py:120-151)
+    def _get_prompt(self, input: str, voice: str, sysprompt=None):
+        return self.prompt_encoder.build_prompt(input, voice, sysprompt)
+
+    def _settings(self, generation_settings):
+        from .config import GenerationSettings
+
+        return generation_settings or GenerationSettings.greedy()
+
+    def generate_codes(self, inputs: List[str], voices: Optional[List[str]] = None, generation_settings=None):
+        """Batched synthesis to audio-code grids: one (n_codebooks, F_b) uint32 array per input."""
+        import numpy as np
+
+        from .generate import BatchGenerator
+
+        voices = voices or ["heart"] * len(inputs)
+        prompts = [self._get_prompt(t, v) for t, v in zip(inputs, voices)]
+        gen = BatchGenerator(self.lm, prompts, self._settings(generation_settings), frames_per_sync=16)
+        cols: List[list] = [[] for _ in inputs]
+        for row in gen:
+            for b, tok in enumerate(row):
+                if tok is not None and tok.audio_codes is not None:
+                    cols[b].append(tok.audio_codes[0, :, 0])
+        gen.close()
+        nq = self.config.num_codebooks
+        return [np.stack(c, axis=1).astype(np.uint32) if c else np.zeros((nq, 0), np.uint32) for c in cols]
+
+    def decode_codes(self, codes) -> "np.ndarray":
+        """(n_codebooks, F) -> float32 PCM (1920 F,)  == codec.decode(gen) of the reference."""
+        import numpy as np
+        import torch
+
+        from .engine import MimiSession
+
+        F_ = int(codes.shape[1])
+        if F_ == 0:
+            return np.zeros(0, np.float32)
+        sess = MimiSession(self.codec, max_batch=1, max_chunk_frames=min(16, F_))
+        dev = torch.from_numpy(np.ascontiguousarray(codes.T.astype(np.int32)))[None].cuda()
+        pcm = sess.decode(dev).cpu().numpy().reshape(-1)
+        sess.close()
+        return pcm
+
+    def __call__(self, input: str, voice: Optional[str] = "heart", speaker=None, generation_settings=None):
+        """Returns flattened float32 PCM (reference __call__, __init__.py:64-81)."""
+        if speaker is not None:
+            raise NotImplementedError("voice-clone speaker prompts (Mimi encoder) are out of this round's scope")
+        codes = self.generate_codes([input], [voice if voice is not None else "heart"], generation_settings)[0]
+        return self.decode_codes(codes)
+
+    def stream(self, input: str, voice: Optional[str] = "heart", generation_settings=None) -> Iterator["np.ndarray"]:
+        """Yields one 1920-sample float32 chunk per generated frame, including the terminating
+        <|im_end|> frame (reference stream, __init__.py:83-95, decodes vq_tensor[:, 1:, :] of every
+        frame).  The codec carries its streaming state, so the chunks concatenate to the batch decode."""
+        import numpy as np
+        import torch
+
+        from .engine import MimiSession
+        from .generate import SingleBatchGenerator
+
+        prompt = self._get_prompt(input, voice if voice is not None else "0")
+        gen = SingleBatchGenerator(self.lm, prompt, self._settings(generation_settings))
+        msess = MimiSession(self.codec, max_batch=1, max_chunk_frames=1)
+        msess.reset()
+        pcm = torch.empty(1, 1920, dtype=torch.float32, device="cuda")
+        nq = self.config.num_codebooks
+        try:
+            for frame in gen:
+                codes = torch.from_numpy(frame.vq_tensor[0, -nq:, 0].astype(np.int32)).reshape(1, 1, nq).cuda()
+                msess.decode_chunk(codes, 0, 1, pcm, code_offset=0)
+                yield pcm.cpu().numpy().reshape(-1).copy()
+        finally:
+            msess.close()
+            gen.close()

@@ -1,0 +1,153 @@
+"""Generation loop façade over the device-side frame loop.
+
+Mirrors mlx_inference/src/smoltts_mlx/lm/generate.py: ``GenerationSettings`` (:12-16), ``VQToken``
+(:19-22), ``SingleBatchGenerator`` (:25-171, an iterator of frames for one utterance) and
+``generate_blocking`` (:174-216).  The reference runs one utterance and synchronises with the
+device nine times per frame; here the frame loop (slow step, 8 depth steps, argmax, column feedback,
+stop rule) runs on the GPU inside ``smoltts_lm_decode`` and the host only fetches finished columns.
+``BatchGenerator`` is the same loop for B utterances at once.
+
+Greedy decoding only in this round (``default_temp == 0`` and no fast temperature): the sampled
+modes of the reference (temperature / min_p, lm/utils/samplers.py) are listed as next in DESIGN.md.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, List, Optional, Sequence
+
+import numpy as np
+
+from .config import GenerationSettings
+from .engine import LMEngine, LMSession
+
+
+@dataclass
+class VQToken:
+    semantic_code: int
+    audio_codes: Optional[Any]  # (1, n_codebooks, 1) uint32 or None (non-semantic slow id)
+    vq_tensor: Any              # (1, 1 + n_fast, 1) uint32
+
+
+def _require_greedy(settings: GenerationSettings) -> None:
+    if not settings.is_greedy:
+        raise NotImplementedError(
+            "smoltts_amd decodes greedily on the device; pass GenerationSettings.greedy() "
+            "(default_temp=0.0, default_fast_temp=0.0). Temperature/min_p sampling is not built yet.")
+
+
+def _frame_to_token(engine: LMEngine, col: np.ndarray) -> VQToken:
+    """lm/generate.py:143-159: audio codes exist only when the slow id is a semantic token."""
+    tc, cfg = engine.token_config, engine.cfg
+    slow = int(col[0])
+    vq = col.astype(np.uint32)[None, :, None]
+    audio = None
+    if tc.semantic_end_id is not None and tc.semantic_start_id <= slow <= tc.semantic_end_id:
+        codes = col[1:] if cfg.duplicate_code_0 else np.concatenate([[slow - tc.semantic_start_id], col[1:]])
+        audio = codes.astype(np.uint32)[None, :, None]
+    return VQToken(semantic_code=slow, audio_codes=audio, vq_tensor=vq)
+
+
+class BatchGenerator:
+    """Frames for B utterances; ``next()`` returns a list with one VQToken (or None once the
+    utterance has stopped) per slot.  ``frames_per_sync`` > 1 lets the GPU run ahead."""
+
+    def __init__(self, engine: LMEngine, prompts: Sequence[np.ndarray], generation_settings: GenerationSettings,
+                 audio_only: bool = True, frames_per_sync: int = 1, session: Optional[LMSession] = None):
+        _require_greedy(generation_settings)
+        self.engine = engine
+        self.settings = generation_settings
+        self.audio_only = audio_only
+        self.B = len(prompts)
+        max_new = generation_settings.max_new_tokens if generation_settings.max_new_tokens is not None else engine.cfg.max_seq_len
+        self.max_frames = max_new + 1  # input_pos counts 0..max_new_tokens inclusive (generate.py:60,161)
+        max_T = max(int(p.shape[1]) for p in prompts)
+        self.session = session or LMSession(engine, self.B, max_seq=min(engine.cfg.max_seq_len, max_T + self.max_frames + 1),
+                                            max_rows=sum(int(p.shape[1]) for p in prompts), max_frames=self.max_frames)
+        self._prompts = list(prompts)
+        self._started = False
+        self._emitted = np.zeros(self.B, dtype=np.int64)
+        self._per_sync = max(1, frames_per_sync)
+        self._pending: List[List[Optional[VQToken]]] = []
+
+    def __iter__(self):
+        return self
+
+    def _run(self) -> None:
+        s = self.session
+        if not self._started:
+            s.prefill(self._prompts, stop_on_eos=self.audio_only)
+            self._started = True
+            if self._per_sync > 1:
+                s.decode(self._per_sync - 1)
+        else:
+            s.decode(self._per_sync)
+        codes, n_frames, done, _ = s.fetch()
+        top = int(n_frames.max())
+        lo = int(self._emitted.min()) if (n_frames > self._emitted).any() else top
+        for f in range(lo, top):
+            row: List[Optional[VQToken]] = []
+            any_new = False
+            for b in range(self.B):
+                if self._emitted[b] <= f < n_frames[b]:
+                    row.append(_frame_to_token(self.engine, codes[b, f]))
+                    any_new = True
+                else:
+                    row.append(None)
+            if any_new:
+                self._pending.append(row)
+        self._emitted = np.maximum(self._emitted, n_frames)
+        self._all_done = bool(done.all())
+
+    def __next__(self) -> List[Optional[VQToken]]:
+        if not self._pending:
+            if self._started and getattr(self, "_all_done", False):
+                raise StopIteration
+            self._run()
+            if not self._pending:
+                raise StopIteration
+        return self._pending.pop(0)
+
+    def close(self) -> None:
+        self.session.close()
+
+
+class SingleBatchGenerator:
+    """One utterance, one frame per ``next()`` (reference class of the same name)."""
+
+    def __init__(self, model: LMEngine, prompt: np.ndarray, generation_settings: GenerationSettings, audio_only: bool = True):
+        prompt = np.asarray(prompt)
+        if prompt.ndim == 3:
+            prompt = prompt[0]
+        self._inner = BatchGenerator(model, [prompt], generation_settings, audio_only=audio_only)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> VQToken:
+        return next(self._inner)[0]
+
+    def close(self) -> None:
+        self._inner.close()
+
+
+def generate_blocking(model: LMEngine, prompt: np.ndarray, generation_settings: GenerationSettings, audio_only: bool = True) -> np.ndarray:
+    """-> (1, n_codebooks, F) uint32 audio codes (frames whose slow id is not semantic are dropped,
+    lm/generate.py:196-207), or the (1, 1+n_fast, F) columns when ``audio_only`` is False."""
+    prompt = np.asarray(prompt)
+    if prompt.ndim == 3:
+        prompt = prompt[0]
+    gen = BatchGenerator(model, [prompt], generation_settings, audio_only=audio_only, frames_per_sync=16)
+    out = []
+    for row in gen:
+        tok = row[0]
+        if tok is None:
+            continue
+        if audio_only:
+            if tok.audio_codes is not None:
+                out.append(tok.audio_codes)
+        else:
+            out.append(tok.vq_tensor)
+    gen.close()
+    if not out:
+        return np.zeros((1, model.cfg.num_codebooks if audio_only else model.grid_height, 0), dtype=np.uint32)
+    return np.concatenate(out, axis=-1)

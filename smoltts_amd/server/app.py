@@ -1,0 +1,128 @@
+"""``smoltts-server`` drop-in: the reference's HTTP surface over the HIP engine.
+
+Routes, schemas, headers and status behaviour follow mlx_inference/src/smoltts_mlx/server/routes/
+openai.py:6-28 (``POST /v1/audio/speech`` -> audio/wav attachment ``speech.wav``) and elevenlabs.py:14-63
+(``POST /v1/text-to-speech/{voice_id}`` blocking with ``output_format`` pcm_*/wav_*; ``.../stream`` ->
+chunked raw float32 PCM with ``X-Sample-Rate: 24000``), ``TTSCore`` (server/tts_core.py:15-84) and the
+settings file (server/settings.py:12-63).  mp3 output and resampling need pydub/soundfile, which the
+reference pulls in and this image lacks: those formats answer 501 instead of being half-implemented.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+from typing import Literal, Optional, Union
+
+import numpy as np
+from fastapi import APIRouter, FastAPI, HTTPException, Query, Request, Response
+from fastapi.responses import StreamingResponse
+from pydantic import BaseModel, Field
+
+from .wav import pcm_to_wav_bytes
+
+
+class TTSCore:
+    def __init__(self, model, settings=None):
+        self.model = model
+        self.settings = settings
+
+    def resolve_speaker_id(self, voice: Union[str, int]) -> int:
+        if isinstance(voice, int):
+            return voice
+        if isinstance(voice, str) and voice.isnumeric():
+            return int(voice)
+        return 0
+
+    def generate_audio(self, input_text: str, voice: Union[str, int], response_format: str = "wav_24000"):
+        pcm = np.asarray(self.model(input_text, str(voice))).flatten()
+        return self.format_audio_chunk(pcm, response_format)
+
+    def stream_audio(self, input_text: str, voice: Union[str, int]):
+        for chunk in self.model.stream(input_text, str(voice)):
+            if chunk is not None:
+                yield np.asarray(chunk, dtype=np.float32).tobytes()
+
+    def format_audio_chunk(self, pcm_data: np.ndarray, output_format: str = "pcm_24000"):
+        kind, _, rate = output_format.partition("_")
+        sample_rate = int(rate.split("_")[0]) if rate else 24000
+        if sample_rate != 24000:
+            raise HTTPException(status_code=501, detail="resampling is not available in this build (24000 Hz only)")
+        if kind == "pcm":
+            return (np.clip(pcm_data, -1.0, 1.0) * 32767).astype(np.int16).tobytes(), "audio/x-pcm"
+        if kind == "wav":
+            return pcm_to_wav_bytes(pcm_data, sample_rate), "audio/wav"
+        if kind == "mp3":
+            raise HTTPException(status_code=501, detail="mp3 output is not available in this build")
+        raise HTTPException(status_code=400, detail=f"Format {output_format} not yet supported")
+
+
+class SpeechRequest(BaseModel):
+    model: str = Field(default="tts-1-hd")
+    input: str
+    voice: Union[str, int] = Field(default="alloy")
+    response_format: Literal["wav"] = Field(default="wav")
+
+
+class CreateSpeechRequest(BaseModel):
+    text: str
+    model_id: Optional[str] = Field(default=None)
+
+
+openai_router = APIRouter(prefix="/v1", tags=["OpenAI"])
+eleven_router = APIRouter(prefix="/v1", tags=["ElevenLabs"])
+
+
+@openai_router.post("/audio/speech")
+async def openai_speech(item: SpeechRequest, http_request: Request):
+    core = http_request.app.state.tts_core
+    audio, media_type = core.generate_audio(item.input, item.voice, item.response_format + "_24000")
+    return Response(audio, media_type=media_type, headers={"Content-Disposition": 'attachment; filename="speech.wav"'})
+
+
+@eleven_router.post("/text-to-speech/{voice_id}")
+async def text_to_speech_blocking(voice_id: str, item: CreateSpeechRequest, http_request: Request,
+                                  output_format: Optional[str] = Query(None, description="pcm_24000 | wav_24000")):
+    core = http_request.app.state.tts_core
+    fmt = output_format or "wav_24000"
+    content, media_type = core.generate_audio(item.text, voice_id, fmt)
+    return Response(content=content, media_type=media_type, headers={
+        "Content-Disposition": f'attachment; filename="elevenlabs_speech.{fmt.split("_")[0]}"',
+        "X-Sample-Rate": fmt.split("_")[1] if "_" in fmt else "24000"})
+
+
+@eleven_router.post("/text-to-speech/{voice_id}/stream")
+async def stream_tts(voice_id: str, item: CreateSpeechRequest, http_request: Request,
+                     output_format: Literal["pcm_24000"] = "pcm_24000"):
+    core = http_request.app.state.tts_core
+    return StreamingResponse(core.stream_audio(item.text, voice=voice_id), media_type="audio/wav", headers={
+        "Content-Disposition": 'attachment; filename="speech.pcm"', "X-Sample-Rate": "24000"})
+
+
+def create_app(model=None, settings: Optional[dict] = None) -> FastAPI:
+    """``model``: a ``smoltts_amd.SmolTTS`` (or any object with ``__call__``/``stream``)."""
+    app = FastAPI()
+    app.include_router(openai_router)
+    app.include_router(eleven_router)
+    app.state.settings = settings
+    app.state.tts_core = TTSCore(model, settings)
+    return app
+
+
+def main():
+    import uvicorn
+
+    from .. import SmolTTS
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=str, help="settings JSON: {checkpoint_dir, mimi_checkpoint, generation{...}, model_type{...}}")
+    ap.add_argument("--port", type=int, default=8000)
+    args = ap.parse_args()
+    settings = json.loads(open(args.config).read()) if args.config else {}
+    if not settings.get("checkpoint_dir"):
+        raise SystemExit("settings must name checkpoint_dir (model_id downloads need network access)")
+    model = SmolTTS(checkpoint_dir=settings["checkpoint_dir"], mimi_checkpoint=settings.get("mimi_checkpoint"))
+    uvicorn.run(create_app(model, settings), host="0.0.0.0", port=args.port)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,83 @@
+"""The reference-shaped façade end to end on the GPU: checkpoint directory (both weight formats) ->
+SmolTTS.__call__ / stream / generate_blocking, against the CPU oracles."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup(tmp_path_factory):
+    from oracle.lm_oracle import LMOracle, OracleLMConfig
+    from oracle.mimi_oracle import MimiDecodeOracle
+    from smoltts_amd import SmolTTS
+    from smoltts_amd.checkpoint import save_checkpoint
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+
+    cfg = named_config("tiny")
+    state = synthetic_lm_state(cfg, seed=11)
+    mst = synthetic_mimi_state(seed=2)
+    d = save_checkpoint(tmp_path_factory.mktemp("ckpt_st"), cfg, state, fmt="safetensors", mlx_layout=True)
+    d2 = save_checkpoint(tmp_path_factory.mktemp("ckpt_pth"), cfg, state, fmt="pth")
+    tts = SmolTTS(checkpoint_dir=str(d), mimi_state=mst)
+    orc = LMOracle(OracleLMConfig.from_dict(cfg.__dict__), state)
+    return cfg, state, mst, tts, orc, MimiDecodeOracle(mst), d2
+
+
+def _rms(a):
+    return float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
+
+
+def test_call_matches_oracle_pipeline(setup):
+    from smoltts_amd.config import GenerationSettings
+
+    cfg, state, mst, tts, orc, morc, _ = setup
+    gs = GenerationSettings.greedy(max_new_tokens=9)
+    pcm = tts("Hello world!", "sky", generation_settings=gs)
+    prompt = tts._get_prompt("Hello world!", "sky")
+    log = orc.generate([torch.from_numpy(prompt)], max_frames=10, stop_on_eos=True)[0]
+    grid = log.as_tensor()  # (9, F)
+    keep = (grid[0] >= 320) & (grid[0] <= 2367)
+    codes = grid[1:, keep]
+    ref = morc.decode(codes[None])[0, 0].numpy()
+    assert pcm.dtype == np.float32 and pcm.shape == ref.shape == (1920 * int(keep.sum()),)
+    assert _rms(pcm - ref) <= 1e-4
+
+
+def test_stream_chunks_concatenate_to_batch_decode(setup):
+    from smoltts_amd.config import GenerationSettings
+
+    cfg, state, mst, tts, orc, morc, _ = setup
+    gs = GenerationSettings.greedy(max_new_tokens=5)
+    chunks = list(tts.stream("streaming", "heart", generation_settings=gs))
+    assert len(chunks) == 6 and all(c.shape == (1920,) and c.dtype == np.float32 for c in chunks)
+    prompt = tts._get_prompt("streaming", "heart")
+    grid = orc.generate([torch.from_numpy(prompt)], max_frames=6, stop_on_eos=True)[0].as_tensor()
+    ref = morc.decode(grid[1:][None])[0, 0].numpy()  # stream decodes every frame's codes (reference __init__.py:88-92)
+    assert _rms(np.concatenate(chunks) - ref) <= 1e-4
+
+
+def test_generate_blocking_and_pth_checkpoint(setup):
+    from smoltts_amd import SmolTTS
+    from smoltts_amd.config import GenerationSettings
+    from smoltts_amd.generate import SingleBatchGenerator, generate_blocking
+
+    cfg, state, mst, tts, orc, morc, d2 = setup
+    tts2 = SmolTTS(checkpoint_dir=str(d2), mimi_state=mst)  # torch-side layout: model.pth, (n, d, 2048) head
+    prompt = tts._get_prompt("same ids from both checkpoint formats", "nova")
+    gs = GenerationSettings.greedy(max_new_tokens=7)
+    a = generate_blocking(tts.lm, prompt[None], gs, audio_only=False)
+    b = generate_blocking(tts2.lm, prompt, gs, audio_only=False)
+    want = orc.generate([torch.from_numpy(prompt)], max_frames=8, stop_on_eos=False)[0].as_tensor().numpy()
+    assert a.shape == (1, 9, 8) and np.array_equal(a, b) and np.array_equal(a[0], want)
+    frames = list(SingleBatchGenerator(tts.lm, prompt, gs))
+    assert len(frames) == 8 and [f.semantic_code for f in frames] == want[0].tolist()
+    for f, col in zip(frames, want.T):
+        sem = 320 <= col[0] <= 2367
+        assert (f.audio_codes is not None) == sem
+        if sem:
+            assert f.audio_codes.shape == (1, 8, 1) and f.audio_codes[0, :, 0].tolist() == col[1:].tolist()
+    with pytest.raises(NotImplementedError):
+        generate_blocking(tts.lm, prompt, GenerationSettings())  # reference default temp 0.7: sampling is not built
