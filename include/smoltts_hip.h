@@ -242,6 +242,9 @@ typedef struct SmolttsGemmArgs {
   int64_t ldr, r_bstride;
   float* out_dev;             /* row m at out + (m / rows_per_batch) * o_bstride + (m % rpb) * ldo */
   int64_t ldo, o_bstride;
+  int32_t elu_out;            /* STORE / RESID: store ELU(result) (the consumer then needs no ELU prologue) */
+  float* raw_out_dev;         /* STORE: optional second copy of the un-activated result, row stride ldo */
+  int64_t raw_bstride;
   /* EPI_QKV_ROPE */
   const float* rope_dev;      /* [pos][32][2] */
   const int32_t* row_pos_dev; /* [M] */

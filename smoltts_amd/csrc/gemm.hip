@@ -36,6 +36,9 @@ struct GemmDev {
   const float* resid;
   float* out;
   long ldo, o_bstride;
+  float* raw_out;  // optional copy of the un-activated result (same row stride, own batch stride)
+  long raw_bstride;
+  int elu_out;     // apply ELU to what goes to `out`
   long ldr, r_bstride;
   const float* rope;
   const int* row_pos;
@@ -225,13 +228,18 @@ __global__ __launch_bounds__(MT >= 4 ? 512 : 1024) void gemm_kernel(GemmDev p) {
 
   if (EPI == SMOLTTS_EPI_STORE) {
     if (n0 + 4 <= p.N) {
+      if (p.raw_out)
+        *reinterpret_cast<float4*>(p.raw_out + row_off(m, p.rows_per_batch, p.ldo, p.raw_bstride) + n0) = make_float4(v[0], v[1], v[2], v[3]);
+      if (p.elu_out) { v[0] = elu1(v[0]); v[1] = elu1(v[1]); v[2] = elu1(v[2]); v[3] = elu1(v[3]); }
       *reinterpret_cast<float4*>(p.out + orow + n0) = make_float4(v[0], v[1], v[2], v[3]);
     } else {  // N < 4 (the final 1-channel conv): scalar tail
       for (int i = 0; i < 4 && n0 + i < p.N; ++i) p.out[orow + n0 + i] = v[i];
     }
   } else if (EPI == SMOLTTS_EPI_RESID) {
     const float4 rr = *reinterpret_cast<const float4*>(p.resid + rrow + n0);
-    *reinterpret_cast<float4*>(p.out + orow + n0) = make_float4(rr.x + v[0], rr.y + v[1], rr.z + v[2], rr.w + v[3]);
+    float4 o = make_float4(rr.x + v[0], rr.y + v[1], rr.z + v[2], rr.w + v[3]);
+    if (p.elu_out) o = make_float4(elu1(o.x), elu1(o.y), elu1(o.z), elu1(o.w));
+    *reinterpret_cast<float4*>(p.out + orow + n0) = o;
   } else if (EPI == SMOLTTS_EPI_SCALE_RESID) {
     const float4 rr = *reinterpret_cast<const float4*>(p.resid + rrow + n0);
     const float4 sc = *reinterpret_cast<const float4*>(p.scale + n0);
@@ -261,6 +269,138 @@ __global__ __launch_bounds__(MT >= 4 ? 512 : 1024) void gemm_kernel(GemmDev p) {
     }
   }
   STAMP(5);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Many-row variant for the Mimi decoder (M = slots x time in the thousands to millions, N <= a few
+// hundred, fp32 weights): the skinny kernel above re-reads the activation rows from L2 for every
+// 16-column tile and needs ~64 B/clk/CU of operands, which the vector-memory path does not deliver.
+// Here a workgroup owns 64*WM rows x 16*NTW*WN columns: each 32-k activation chunk goes through LDS
+// once (in B-fragment order, read back conflict-free with two ds_read_b128 per fragment) and is shared
+// by the WN waves that hold different column tiles; every wave accumulates the whole K itself, so
+// there is no cross-wave reduction and the epilogue stores straight from the accumulators.
+template <int NTW, int EPI>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(GemmDev p, int WN) {
+  __shared__ __attribute__((aligned(16))) float xs[4 * 4 * 64 * 8];  // [row group][q][row][8]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int WM = 4 / WN;
+  const int wn = wave % WN, wm = wave / WN;
+  const int nchunks = p.K >> 5;
+  const int row0 = blockIdx.y * 64 * WM;
+  const int tile0 = (blockIdx.x * WN + wn) * NTW;
+
+  // staging assignment: 2*WM float4 per thread and chunk
+  const float* sp[8];
+  int sdst[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = tid + 256 * i;
+    const int rg = idx >> 9, row = (idx & 511) >> 3, kq = idx & 7;
+    const int m = row0 + rg * 64 + row;
+    const bool v = i < 2 * WM && m < p.M;
+    sp[i] = v ? p.x + row_off(m, p.rows_per_batch, p.ldx, p.x_bstride) + kq * 4 : nullptr;
+    sdst[i] = ((rg * 4 + (kq >> 1)) * 64 + row) * 8 + (kq & 1) * 4;
+  }
+  const char* wb[NTW];
+  bool wv[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    wv[t] = (tile0 + t) * 16 < p.N;
+    wb[t] = p.w + (size_t)(tile0 + t) * nchunks * 2048 + lane * 16;
+  }
+  f32x4 acc[NTW][4];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 stage[8];
+  uint4 wnext[NTW][2];
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      stage[i] = (i < 2 * WM && sp[i]) ? *reinterpret_cast<const float4*>(sp[i] + c * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      wnext[t][0] = wv[t] ? *reinterpret_cast<const uint4*>(wb[t] + (size_t)c * 2048) : make_uint4(0, 0, 0, 0);
+      wnext[t][1] = wv[t] ? *reinterpret_cast<const uint4*>(wb[t] + (size_t)c * 2048 + 1024) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  fetch(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();  // previous chunk fully consumed
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < 2 * WM) *reinterpret_cast<float4*>(xs + sdst[i]) = stage[i];
+    float wcur[NTW][8];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      wcur[t][0] = __uint_as_float(wnext[t][0].x); wcur[t][1] = __uint_as_float(wnext[t][0].y);
+      wcur[t][2] = __uint_as_float(wnext[t][0].z); wcur[t][3] = __uint_as_float(wnext[t][0].w);
+      wcur[t][4] = __uint_as_float(wnext[t][1].x); wcur[t][5] = __uint_as_float(wnext[t][1].y);
+      wcur[t][6] = __uint_as_float(wnext[t][1].z); wcur[t][7] = __uint_as_float(wnext[t][1].w);
+    }
+    __syncthreads();
+    if (c + 1 < nchunks) fetch(c + 1);  // next chunk's global loads fly under this chunk's MFMAs
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const float* xp = xs + ((wm * 4 + q) * 64 + mt * 16 + r) * 8;
+      const float4 x0 = *reinterpret_cast<const float4*>(xp), x1 = *reinterpret_cast<const float4*>(xp + 4);
+      const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+      for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[t][j], xv[j], acc[t][mt], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue straight from the accumulators: lane holds out[m = rows + mt*16 + r][n0 .. n0+4)
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = row0 + wm * 64 + mt * 16 + r;
+    if (m >= p.M) continue;
+    const long orow = row_off(m, p.rows_per_batch, p.ldo, p.o_bstride);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int n0 = (tile0 + t) * 16 + q * 4;
+      if (n0 >= p.N) continue;
+      float v[4] = {acc[t][mt][0], acc[t][mt][1], acc[t][mt][2], acc[t][mt][3]};
+      if (p.bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (n0 + i < p.N) v[i] += p.bias[n0 + i];
+      }
+      if (n0 + 4 > p.N) {  // N < 4: scalar tail (the 1-channel output conv)
+        for (int i = 0; i < 4 && n0 + i < p.N; ++i) p.out[orow + n0 + i] = p.elu_out ? elu1(v[i]) : v[i];
+        continue;
+      }
+      if (EPI == SMOLTTS_EPI_RESID) {
+        const float4 rr = *reinterpret_cast<const float4*>(p.resid + row_off(m, p.rows_per_batch, p.ldr, p.r_bstride) + n0);
+        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+      } else if (p.raw_out) {
+        *reinterpret_cast<float4*>(p.raw_out + row_off(m, p.rows_per_batch, p.ldo, p.raw_bstride) + n0) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+      if (p.elu_out) { v[0] = elu1(v[0]); v[1] = elu1(v[1]); v[2] = elu1(v[2]); v[3] = elu1(v[3]); }
+      *reinterpret_cast<float4*>(p.out + orow + n0) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+template <int EPI>
+static int launch_rows(const GemmDev& d, hipStream_t stream) {
+  const int ntiles = (d.N + 15) / 16;
+  const int NTW = ntiles >= 16 ? 4 : (ntiles >= 8 ? 2 : 1);
+  const int per = (ntiles + NTW - 1) / NTW;       // column-tile groups a workgroup could hold
+  const int WN = per >= 4 ? 4 : (per >= 2 ? 2 : 1);
+  const int WM = 4 / WN;
+  const dim3 grid((per + WN - 1) / WN, (d.M + 64 * WM - 1) / (64 * WM));
+  ST_REQUIRE(grid.y <= 65535, SMOLTTS_E_INVALID, "gemm: M=%d too large for one launch", d.M);
+  if (NTW == 4) hipLaunchKernelGGL((gemm_rows_kernel<4, EPI>), grid, dim3(256), 0, stream, d, WN);
+  else if (NTW == 2) hipLaunchKernelGGL((gemm_rows_kernel<2, EPI>), grid, dim3(256), 0, stream, d, WN);
+  else hipLaunchKernelGGL((gemm_rows_kernel<1, EPI>), grid, dim3(256), 0, stream, d, WN);
+  ST_CHECK_HIP(hipGetLastError());
+  return SMOLTTS_OK;
 }
 
 template <bool WF32, int MT, int U, int PRO, int EPI>
@@ -330,6 +470,7 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
   d.w = (const char*)a.w_dev; d.x = a.x_dev; d.ldx = a.ldx; d.x_bstride = a.x_bstride;
   d.rows_per_batch = a.rows_per_batch; d.M = a.M; d.N = a.N; d.K = a.K; d.gamma = a.gamma_dev; d.eps = a.eps;
   d.bias = a.bias_dev; d.scale = a.scale_dev; d.resid = a.resid_dev; d.out = a.out_dev; d.ldo = a.ldo;
+  d.raw_out = a.raw_out_dev; d.raw_bstride = a.raw_bstride; d.elu_out = a.elu_out;
   d.o_bstride = a.o_bstride; d.ldr = a.ldr ? a.ldr : a.ldo; d.r_bstride = a.ldr ? a.r_bstride : a.o_bstride;
   d.rope = a.rope_dev; d.row_pos = a.row_pos_dev; d.row_slot = a.row_slot_dev;
   d.kc = a.k_cache_dev; d.vc = a.v_cache_dev; d.n_q_heads = a.n_q_heads; d.n_kv_heads = a.n_kv_heads;
@@ -354,6 +495,10 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
   else
     ST_REQUIRE(a.out_dev, SMOLTTS_E_INVALID, "gemm: null output");
 
+  if (a.w_is_fp32 && P == SMOLTTS_PRO_NONE && a.M >= 1024 && (E == SMOLTTS_EPI_STORE || E == SMOLTTS_EPI_RESID)) {
+    ST_REQUIRE((long)((a.M + 63) / 64) <= 65535 * 4L, SMOLTTS_E_INVALID, "gemm: M=%d too large for one launch", a.M);
+    return E == SMOLTTS_EPI_STORE ? launch_rows<SMOLTTS_EPI_STORE>(d, stream) : launch_rows<SMOLTTS_EPI_RESID>(d, stream);
+  }
 #define ST_CASE(WF, PP, EE)                                                       \
   if ((a.w_is_fp32 != 0) == WF && P == PP && E == EE) return launch_mt<WF, PP, EE>(d, nwaves, stream);
   // bf16 weights: the DualAR transformer
@@ -367,6 +512,7 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
   ST_CASE(true, SMOLTTS_PRO_NONE, SMOLTTS_EPI_SCALE_RESID)
   ST_CASE(true, SMOLTTS_PRO_NONE, SMOLTTS_EPI_GELU)
   ST_CASE(true, SMOLTTS_PRO_NONE, SMOLTTS_EPI_STORE)
+  ST_CASE(true, SMOLTTS_PRO_NONE, SMOLTTS_EPI_RESID)
   ST_CASE(true, SMOLTTS_PRO_ELU, SMOLTTS_EPI_STORE)
   ST_CASE(true, SMOLTTS_PRO_ELU, SMOLTTS_EPI_RESID)
 #undef ST_CASE

@@ -47,6 +47,8 @@ struct SmolttsMimiSession {
   int *row_pos, *row_slot;  // [B*2*chunk]
   float* buf[NBUF];
   size_t buf_bstride[NBUF];  // floats per slot
+  float* raw[4];             // un-activated ConvTranspose outputs (residual inputs of the 4 resnet blocks)
+  size_t raw_bstride[4];
   size_t halo_total;         // bytes of everything that reset must zero: tracked via pointers below
   char* zero_begin;
   size_t zero_bytes;
@@ -83,6 +85,11 @@ void carve(SmolttsMimiSession* s, char* base, size_t* total) {
   }
   s->zero_begin = base ? base + z0 : nullptr;
   s->zero_bytes = cv.off - z0;
+  for (int j = 0; j < 4; ++j) {  // raw copies of buffers 2, 5, 8, 11 (no halo: only read row-aligned)
+    const int i = 2 + 3 * j;
+    s->raw_bstride[j] = (size_t)BUF_RPF[i] * F * BUF_C[i];
+    s->raw[j] = cv.take<float>(B * s->raw_bstride[j]);
+  }
   // --- scratch / caches (need no zeroing: only positions < `positions` are ever read)
   s->tx = cv.take<float>(R * D);
   s->tn = cv.take<float>(R * D);
@@ -297,7 +304,10 @@ int smoltts_mimi_decode_chunk(SmolttsMimiSession* s, const int32_t* codes_dev, i
     }
   }
 
-  // 3. SEANet decoder (seanet.py:105-139) as 14 GEMMs over halo-prefixed channel-last buffers
+  // 3. SEANet decoder (seanet.py:105-139) as 14 GEMMs over halo-prefixed channel-last buffers.
+  //    Every buffer holds ELU(activation) (each consumer applies ELU first, seanet.py:16-20,117-137), so the
+  //    activation is computed once by the producer; the un-activated ConvTranspose output is kept
+  //    beside it for the resnet block's residual add.
   for (int i = 0; i < NCONV; ++i) {
     const SmolttsMimiConv& cv = m->w.convs[i];
     const int Tin = BUF_RPF[i] * F;
@@ -306,19 +316,25 @@ int smoltts_mimi_decode_chunk(SmolttsMimiSession* s, const int32_t* codes_dev, i
     SmolttsGemmArgs a = gemm_f32(A + cv.w, s->buf[i], cv.cin, batch * Tin, N, K);
     a.rows_per_batch = Tin; a.x_bstride = (int64_t)s->buf_bstride[i];
     a.bias_dev = (const float*)(A + cv.b);
-    a.prologue = i == 0 ? SMOLTTS_PRO_NONE : SMOLTTS_PRO_ELU;
+    a.prologue = SMOLTTS_PRO_NONE;
     a.epilogue = SMOLTTS_EPI_STORE;
     if (i + 1 < NCONV) {
       a.out_dev = s->buf[i + 1] + (size_t)BUF_HALO[i + 1] * BUF_C[i + 1];
       a.ldo = N; a.o_bstride = (int64_t)s->buf_bstride[i + 1];
+      a.elu_out = 1;
     } else {
       a.out_dev = pcm_dev; a.ldo = 1; a.o_bstride = pcm_stride;
     }
+    if (cv.transposed) {  // i = 1, 4, 7, 10 -> raw copy j = (i - 1) / 3
+      const int j = (i - 1) / 3;
+      a.raw_out_dev = s->raw[j]; a.raw_bstride = (int64_t)s->raw_bstride[j];
+    }
     const bool res_c1 = i >= 3 && i <= 12 && (i % 3) == 0;  // second conv of a residual block: + block input
     if (res_c1) {
+      const int j = i / 3 - 1;
       a.epilogue = SMOLTTS_EPI_RESID;
-      a.resid_dev = s->buf[i - 1] + (size_t)BUF_HALO[i - 1] * BUF_C[i - 1];
-      a.ldr = BUF_C[i - 1]; a.r_bstride = (int64_t)s->buf_bstride[i - 1];
+      a.resid_dev = s->raw[j];
+      a.ldr = BUF_C[i - 1]; a.r_bstride = (int64_t)s->raw_bstride[j];
     }
     ST_TRY(launch_gemm(a, st));
   }

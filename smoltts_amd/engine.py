@@ -51,7 +51,8 @@ class GemmArgs(C.Structure):
         ("x_bstride", C.c_int64), ("rows_per_batch", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
         ("K", C.c_int32), ("prologue", C.c_int32), ("epilogue", C.c_int32), ("gamma_dev", C.c_void_p),
         ("eps", C.c_float), ("bias_dev", C.c_void_p), ("scale_dev", C.c_void_p), ("resid_dev", C.c_void_p),
-        ("ldr", C.c_int64), ("r_bstride", C.c_int64), ("out_dev", C.c_void_p), ("ldo", C.c_int64), ("o_bstride", C.c_int64), ("rope_dev", C.c_void_p),
+        ("ldr", C.c_int64), ("r_bstride", C.c_int64), ("out_dev", C.c_void_p), ("ldo", C.c_int64), ("o_bstride", C.c_int64),
+        ("elu_out", C.c_int32), ("raw_out_dev", C.c_void_p), ("raw_bstride", C.c_int64), ("rope_dev", C.c_void_p),
         ("row_pos_dev", C.c_void_p), ("row_slot_dev", C.c_void_p), ("k_cache_dev", C.c_void_p),
         ("v_cache_dev", C.c_void_p), ("n_q_heads", C.c_int32), ("n_kv_heads", C.c_int32), ("cache_len", C.c_int32),
     ]

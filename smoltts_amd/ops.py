@@ -31,7 +31,8 @@ def linear(x: torch.Tensor, w_tiles: torch.Tensor, N: int, *, w_fp32: bool = Fal
            rows_per_batch: int = 0, ldo: Optional[int] = None, o_bstride: int = 0, ldr: int = 0, r_bstride: int = 0,
            rope: Optional[torch.Tensor] = None, row_pos: Optional[torch.Tensor] = None,
            row_slot: Optional[torch.Tensor] = None, k_cache: Optional[torch.Tensor] = None,
-           v_cache: Optional[torch.Tensor] = None, n_q_heads: int = 0, n_kv_heads: int = 0, cache_len: int = 0) -> torch.Tensor:
+           v_cache: Optional[torch.Tensor] = None, n_q_heads: int = 0, n_kv_heads: int = 0, cache_len: int = 0,
+           elu_out: bool = False, raw_out: Optional[torch.Tensor] = None, raw_bstride: int = 0) -> torch.Tensor:
     lib = E.load_library()
     M = x.shape[0] if M is None else M
     K = x.shape[1] if K is None else K
@@ -48,6 +49,7 @@ def linear(x: torch.Tensor, w_tiles: torch.Tensor, N: int, *, w_fp32: bool = Fal
     a.out_dev = E.dptr(out)
     a.ldo = (out.stride(0) if out.dim() == 2 else out_cols) if ldo is None else ldo
     a.o_bstride = o_bstride
+    a.elu_out, a.raw_out_dev, a.raw_bstride = int(elu_out), E.dptr(raw_out), raw_bstride
     a.rope_dev, a.row_pos_dev, a.row_slot_dev = E.dptr(rope), E.dptr(row_pos), E.dptr(row_slot)
     a.k_cache_dev, a.v_cache_dev = E.dptr(k_cache), E.dptr(v_cache)
     a.n_q_heads, a.n_kv_heads, a.cache_len = n_q_heads, n_kv_heads, cache_len

@@ -250,3 +250,52 @@ def test_layernorm(E, ops):
     w, b = torch.randn(512, generator=g), torch.randn(512, generator=g)
     out = ops.layernorm(x.cuda(), w.cuda(), b.cuda()).cpu()
     assert rel_err(out, F.layer_norm(x, (512,), w, b, 1e-5)) < 1e-5
+
+
+@pytest.mark.parametrize("B,T,cin,cout,k", [(4, 480, 128, 64, 1), (2, 900, 64, 32, 3), (3, 400, 256, 128, 3), (2, 1100, 32, 64, 1)])
+def test_many_row_conv_with_fused_output_activation(E, ops, B, T, cin, cout, k):
+    """M >= 1024 takes the LDS-staged many-row kernel; the producer stores ELU(out) (+ the raw copy)."""
+    from smoltts_amd.packing import conv_as_gemm
+
+    g = torch.Generator().manual_seed(cin + cout + k)
+    x = torch.randn(B, cin, T, generator=g)
+    w = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv1d(F.pad(x, (k - 1, 0)), w, b).transpose(1, 2)  # B,T,cout
+    halo = k - 1
+    buf = torch.zeros(B, halo + T, cin)
+    buf[:, halo:] = x.transpose(1, 2)
+    gw, gb = conv_as_gemm(w, b, False, 1)
+    out = torch.zeros(B, T, cout).cuda()
+    raw = torch.zeros(B, T, cout).cuda()
+    ops.linear(buf.cuda(), ops.pack_weight(gw, fp32=True), cout, w_fp32=True, epilogue=E.EPI_STORE, bias=gb.cuda(), out=out,
+               M=B * T, K=k * cin, ldx=cin, x_bstride=(halo + T) * cin, rows_per_batch=T, ldo=cout, o_bstride=T * cout,
+               elu_out=True, raw_out=raw, raw_bstride=T * cout)
+    assert rel_err(raw.cpu(), ref) < 3e-5
+    assert rel_err(out.cpu(), F.elu(ref)) < 3e-5
+    # residual form: out = ELU(resid + conv)
+    res = torch.randn(B, T, cout, generator=g)
+    out2 = torch.zeros(B, T, cout).cuda()
+    ops.linear(buf.cuda(), ops.pack_weight(gw, fp32=True), cout, w_fp32=True, epilogue=E.EPI_RESID, bias=gb.cuda(), out=out2,
+               resid=res.cuda(), M=B * T, K=k * cin, ldx=cin, x_bstride=(halo + T) * cin, rows_per_batch=T, ldo=cout,
+               o_bstride=T * cout, ldr=cout, r_bstride=T * cout, elu_out=True)
+    assert rel_err(out2.cpu(), F.elu(res + ref)) < 3e-5
+
+
+def test_many_row_convtranspose(E, ops):
+    from smoltts_amd.packing import conv_as_gemm
+
+    g = torch.Generator().manual_seed(77)
+    B, T, cin, cout, s = 3, 700, 128, 64, 4
+    x = torch.randn(B, cin, T, generator=g)
+    w = torch.randn(cin, cout, 2 * s, generator=g) / math.sqrt(cin)
+    b = torch.randn(cout, generator=g)
+    y = F.conv_transpose1d(x, w, b, stride=s)
+    ref = y[..., : y.shape[-1] - s].transpose(1, 2)
+    buf = torch.zeros(B, 1 + T, cin)
+    buf[:, 1:] = x.transpose(1, 2)
+    gw, gb = conv_as_gemm(w, b, True, s)
+    out = torch.zeros(B, T * s, cout).cuda()
+    ops.linear(buf.cuda(), ops.pack_weight(gw, fp32=True), s * cout, w_fp32=True, epilogue=E.EPI_STORE, bias=gb.cuda(), out=out,
+               M=B * T, K=2 * cin, ldx=cin, x_bstride=(1 + T) * cin, rows_per_batch=T, ldo=s * cout, o_bstride=T * s * cout)
+    assert rel_err(out.cpu(), ref) < 3e-5
