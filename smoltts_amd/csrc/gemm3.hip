@@ -70,35 +70,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
   constexpr bool kRope = EPI == SMOLTTS_EPI_QKV_ROPE;
   STAMP3(0);
 
-  // ---- epilogue inputs of the waves that will finish the tiles (waves < MT): every load is issued
-  //      here, ahead of the operand stream, so that the tail of the kernel waits on nothing
-  const bool fin = wave < MT;
+  const bool fin = wave < MT;  // waves that will finish the tiles
   const int m = (mg * MT + wave) * 16 + r;  // meaningful for fin waves only
   const bool mvalid = fin && m < p.M;
-  int pos = 0, slot = 0;
-  float ssv[16];
-  float4 rr[T], bb[T], ga[T], gb[T];
-  if (fin) {
-    if (kRope && mvalid) { pos = p.row_pos[m]; slot = p.row_slot[m]; }
-    const int nt_in = p.K >> 4;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int i = q + 4 * j;
-      ssv[j] = (p.ssq_in != nullptr && mvalid && i < nt_in) ? p.ssq_in[(size_t)m * nt_in + i] : 0.f;
-    }
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const int n0 = (ng * T + t) * 16 + q * 4;
-      const bool valid = mvalid && n0 < p.N;
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      rr[t] = (kResid && valid) ? *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldo + n0) : z;
-      bb[t] = (p.bias != nullptr && valid) ? *reinterpret_cast<const float4*>(p.bias + n0) : z;
-      ga[t] = (kEmits && p.emit.x3a && p.emit.gamma_a && valid) ? *reinterpret_cast<const float4*>(p.emit.gamma_a + n0)
-                                                                : make_float4(1.f, 1.f, 1.f, 1.f);
-      gb[t] = (kEmits && p.emit.x3b && p.emit.gamma_b && valid) ? *reinterpret_cast<const float4*>(p.emit.gamma_b + n0)
-                                                                : make_float4(1.f, 1.f, 1.f, 1.f);
-    }
-  }
 
   f32x4 acc[T][MT];
   const char* xb[MT];
@@ -120,9 +94,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
     for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
-  for (int c0 = wave; c0 < nchunks; c0 += nwaves * U) {
-    uint4 xf[U][MT][3];
-    uint4 wf[U][T];
+  uint4 xf[U][MT][3];
+  uint4 wf[U][T];
+  auto load_group = [&](int c0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int c = c0 + u * nwaves;
@@ -138,6 +112,44 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
                                          : make_uint4(0, 0, 0, 0);
       }
     }
+  };
+  // the operand stream goes out first ...
+  load_group(wave);
+
+  // ... then the epilogue inputs of the finishing waves, all issued here so that the tail of the
+  // kernel waits on nothing
+  int pos = 0, slot = 0;
+  float ssv[16];
+  float4 rr[T], bb[T], ga[T], gb[T];
+  if (fin) {  // wave-uniform branches, clamped (always valid) addresses: no per-lane control flow
+    const int mc = m < p.M ? m : p.M - 1;
+    if (kRope) { pos = p.row_pos[mc]; slot = p.row_slot[mc]; }
+    const int nt_in = p.K >> 4;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) ssv[j] = 0.f;
+    if (p.ssq_in != nullptr) {
+      const float* sp = p.ssq_in + (size_t)mc * nt_in;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int i = q + 4 * j;
+        const float vld = sp[i < nt_in ? i : nt_in - 1];
+        ssv[j] = i < nt_in ? vld : 0.f;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int n0r = (ng * T + t) * 16 + q * 4;
+      const int n0 = n0r < p.N ? n0r : p.N - 4;  // N % 4 == 0
+      rr[t] = bb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      ga[t] = gb[t] = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (kResid) rr[t] = *reinterpret_cast<const float4*>(p.resid + (long)mc * p.ldo + n0);
+      if (p.bias != nullptr) bb[t] = *reinterpret_cast<const float4*>(p.bias + n0);
+      if (kEmits && p.emit.x3a && p.emit.gamma_a) ga[t] = *reinterpret_cast<const float4*>(p.emit.gamma_a + n0);
+      if (kEmits && p.emit.x3b && p.emit.gamma_b) gb[t] = *reinterpret_cast<const float4*>(p.emit.gamma_b + n0);
+    }
+  }
+
+  for (int c0 = wave; c0 < nchunks;) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -151,6 +163,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
         }
       }
     }
+    c0 += nwaves * U;
+    if (c0 < nchunks) load_group(c0);
   }
 
   STAMP3(1);
@@ -192,15 +206,16 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
     s += __shfl_xor(s, 32);
     rstd = 1.0f / sqrtf(s / (float)p.K + p.eps);
   }
+  if (kRope && !mvalid) pos = -1;
 
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    float4 part[16];
+    float4 part[8];  // workgroups have at most 8 waves (launch3_epi)
 #pragma unroll
-    for (int w = 0; w < 16; ++w) part[w] = red4[(((w < nwaves ? w : 0) * T + t) * MT + mt) * 64 + lane];
+    for (int w = 0; w < 8; ++w) part[w] = red4[(((w < nwaves ? w : 0) * T + t) * MT + mt) * 64 + lane];
     float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
+    for (int w = 0; w < 8; ++w) {
       const bool on = w < nwaves;
       v[0] += on ? part[w].x : 0.f;
       v[1] += on ? part[w].y : 0.f;
