@@ -10,8 +10,7 @@
 // The cache is fp32 [slot][kv head][cache_len][64], so a key is 256 contiguous bytes: 16 lanes x
 // float4 read one key and a wave reads 4 keys per instruction (1 KiB, coalesced), four such loads
 // in flight per wave.  Short caches (the 8-entry depth-transformer cache) run 4 waves, long ones 16.
-// Two passes with the scores parked in LDS (exact softmax: max, exp, sum in a fixed reduction
-// order => deterministic), then P.V with the same lane mapping and a fixed-order cross-wave sum.
+// Softmax is computed online per lane group and merged in a fixed order (deterministic).
 // The result is written as fp32 rows and/or directly as the X3 operand of the following wo GEMM.
 #include "x3.h"
 
@@ -39,15 +38,18 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-constexpr int ATT_UNROLL = 4;
+constexpr int ATT_UN = 8;  // keys per lane group and pass: 8 K + 8 V rows in flight per wave
 
+// Long caches: single pass with an online softmax per lane group (4 groups x nwaves per workgroup, each
+// owning every (4*nwaves)-th key), K and V rows of a pass all in flight together, one rescale per
+// 8-key block (9 exps per 8 keys and head); the groups' (max, sum, acc) triples are merged in fixed
+// order: the 4 groups of a wave with shuffles, the waves through LDS.  Two barriers in total.
 template <int G>
 __global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int nwaves = blockDim.x >> 6;
-  float* scores = smem;                      // [G][score_cap]
-  float* part = smem + G * p.score_cap;      // [16 waves][G][64]
-  float* stat = part + 16 * G * 64;          // [16][G]
+  float* part = smem;                  // [16 waves][G][64]
+  float* stat = smem + 16 * G * 64;    // [16 waves][G][2] (max, sum)
   const int row = blockIdx.x, h = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int kk = lane >> 4, dl = lane & 15;
@@ -64,8 +66,8 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
   const int j_lo = (p.window > 0 && pos + 1 > p.window) ? pos + 1 - p.window : 0;
   const int L = pos + 1 - j_lo;
   const long cbase = (((long)slot * p.n_kv_heads + h) * p.cache_len + j_lo) * 64;
-  const float* K = p.kc + cbase;
-  const float* V = p.vc + cbase;
+  const float* K = p.kc + cbase + dl * 4;
+  const float* V = p.vc + cbase + dl * 4;
   const int step = 4 * nwaves;
 
   float4 qv[G];
@@ -74,111 +76,88 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
     float4 t = *reinterpret_cast<const float4*>(p.q + (long)row * HD + (h * G + g) * 64 + dl * 4);
     qv[g] = make_float4(t.x * 0.125f, t.y * 0.125f, t.z * 0.125f, t.w * 0.125f);
   }
-
-  // ---- pass 1: scores
-  for (int j0 = wave * 4; j0 < L; j0 += step * ATT_UNROLL) {
-    float4 kv[ATT_UNROLL];
-#pragma unroll
-    for (int u = 0; u < ATT_UNROLL; ++u) {
-      const int j = j0 + u * step + kk;
-      kv[u] = j < L ? *reinterpret_cast<const float4*>(K + (long)j * 64 + dl * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int u = 0; u < ATT_UNROLL; ++u) {
-      const int j = j0 + u * step + kk;
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        float s = qv[g].x * kv[u].x;
-        s = fmaf(qv[g].y, kv[u].y, s);
-        s = fmaf(qv[g].z, kv[u].z, s);
-        s = fmaf(qv[g].w, kv[u].w, s);
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        s += __shfl_xor(s, 8);
-        if (j < L && dl == 0) scores[g * p.score_cap + j] = s;
-      }
-    }
-  }
-  __syncthreads();
-  // ---- max
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    float m = -INFINITY;
-    for (int j = tid; j < L; j += blockDim.x) m = fmaxf(m, scores[g * p.score_cap + j]);
-    m = wave_max(m);
-    if (lane == 0) stat[wave * G + g] = m;
-  }
-  __syncthreads();
-  float gmax[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    float m = stat[g];
-    for (int w = 1; w < nwaves; ++w) m = fmaxf(m, stat[w * G + g]);
-    gmax[g] = m;
-  }
-  __syncthreads();
-  // ---- exp + sum
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    float s = 0.f;
-    for (int j = tid; j < L; j += blockDim.x) {
-      const float e = expf(scores[g * p.score_cap + j] - gmax[g]);
-      scores[g * p.score_cap + j] = e;
-      s += e;
-    }
-    s = wave_sum(s);
-    if (lane == 0) stat[wave * G + g] = s;
-  }
-  __syncthreads();
-
-  // ---- pass 2: P.V
+  float mx[G], den[G];
   float4 acc[G];
 #pragma unroll
-  for (int g = 0; g < G; ++g) acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int j0 = wave * 4; j0 < L; j0 += step * ATT_UNROLL) {
-    float4 vv[ATT_UNROLL];
+  for (int g = 0; g < G; ++g) { mx[g] = -INFINITY; den[g] = 0.f; acc[g] = make_float4(0.f, 0.f, 0.f, 0.f); }
+
+  for (int j0 = wave * 4 + kk; j0 < L + kk; j0 += step * ATT_UN) {  // (+kk keeps the trip count wave-uniform)
+    float4 kv[ATT_UN], vv[ATT_UN];
 #pragma unroll
-    for (int u = 0; u < ATT_UNROLL; ++u) {
-      const int j = j0 + u * step + kk;
-      vv[u] = j < L ? *reinterpret_cast<const float4*>(V + (long)j * 64 + dl * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < ATT_UN; ++u) {
+      const int j = j0 + u * step;
+      const bool ok = j < L;
+      kv[u] = ok ? *reinterpret_cast<const float4*>(K + (long)j * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+      vv[u] = ok ? *reinterpret_cast<const float4*>(V + (long)j * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int u = 0; u < ATT_UNROLL; ++u) {
-      const int j = j0 + u * step + kk;
-      if (j < L) {
+    for (int g = 0; g < G; ++g) {
+      float s[ATT_UN];
+      float bm = -INFINITY;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const float pj = scores[g * p.score_cap + j];
-          acc[g].x = fmaf(pj, vv[u].x, acc[g].x);
-          acc[g].y = fmaf(pj, vv[u].y, acc[g].y);
-          acc[g].z = fmaf(pj, vv[u].z, acc[g].z);
-          acc[g].w = fmaf(pj, vv[u].w, acc[g].w);
+      for (int u = 0; u < ATT_UN; ++u) {
+        float t = qv[g].x * kv[u].x;
+        t = fmaf(qv[g].y, kv[u].y, t);
+        t = fmaf(qv[g].z, kv[u].z, t);
+        t = fmaf(qv[g].w, kv[u].w, t);
+        t += __shfl_xor(t, 1);
+        t += __shfl_xor(t, 2);
+        t += __shfl_xor(t, 4);
+        t += __shfl_xor(t, 8);
+        s[u] = (j0 + u * step < L) ? t : -INFINITY;
+        bm = fmaxf(bm, s[u]);
+      }
+      if (bm > -INFINITY) {  // uniform inside the 16-lane group
+        const float mn = fmaxf(mx[g], bm);
+        const float sc = expf(mx[g] - mn);  // exp(-inf) = 0 on the first block
+        float d = den[g] * sc;
+        float4 a = make_float4(acc[g].x * sc, acc[g].y * sc, acc[g].z * sc, acc[g].w * sc);
+#pragma unroll
+        for (int u = 0; u < ATT_UN; ++u) {
+          const float e = expf(s[u] - mn);  // masked keys: exp(-inf) = 0
+          d += e;
+          a.x = fmaf(e, vv[u].x, a.x); a.y = fmaf(e, vv[u].y, a.y); a.z = fmaf(e, vv[u].z, a.z); a.w = fmaf(e, vv[u].w, a.w);
         }
+        mx[g] = mn; den[g] = d; acc[g] = a;
       }
     }
   }
+
+  // ---- merge the 4 lane groups of the wave (fixed order: xor 16, then xor 32)
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    float4 a = acc[g];
-    a.x += __shfl_xor(a.x, 16); a.y += __shfl_xor(a.y, 16); a.z += __shfl_xor(a.z, 16); a.w += __shfl_xor(a.w, 16);
-    a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
-    if (kk == 0) *reinterpret_cast<float4*>(part + (wave * G + g) * 64 + dl * 4) = a;
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      const float om = __shfl_xor(mx[g], o), od = __shfl_xor(den[g], o);
+      const float ox = __shfl_xor(acc[g].x, o), oy = __shfl_xor(acc[g].y, o), oz = __shfl_xor(acc[g].z, o), ow = __shfl_xor(acc[g].w, o);
+      const float mn = fmaxf(mx[g], om);
+      const float sa = mn > -INFINITY ? expf(mx[g] - mn) : 0.f, sb = mn > -INFINITY ? expf(om - mn) : 0.f;
+      den[g] = den[g] * sa + od * sb;
+      acc[g] = make_float4(acc[g].x * sa + ox * sb, acc[g].y * sa + oy * sb, acc[g].z * sa + oz * sb, acc[g].w * sa + ow * sb);
+      mx[g] = mn;
+    }
+    if (kk == 0) *reinterpret_cast<float4*>(part + (wave * G + g) * 64 + dl * 4) = acc[g];
+    if (lane == 0) { stat[(wave * G + g) * 2] = mx[g]; stat[(wave * G + g) * 2 + 1] = den[g]; }
   }
   __syncthreads();
+  // ---- merge the waves
   if (tid < G * 16) {
     const int g = tid >> 4, d4 = (tid & 15) * 4;
-    float4 s = *reinterpret_cast<const float4*>(part + g * 64 + d4);
-    float den = stat[g];
-    for (int w = 1; w < nwaves; ++w) {
+    float gm = -INFINITY;
+    for (int w = 0; w < nwaves; ++w) gm = fmaxf(gm, stat[(w * G + g) * 2]);
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dsum = 0.f;
+    for (int w = 0; w < nwaves; ++w) {
+      const float wm = stat[(w * G + g) * 2];
+      const float sc = wm > -INFINITY ? expf(wm - gm) : 0.f;
       const float4 t = *reinterpret_cast<const float4*>(part + (w * G + g) * 64 + d4);
-      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-      den += stat[w * G + g];
+      sum.x = fmaf(t.x, sc, sum.x); sum.y = fmaf(t.y, sc, sum.y); sum.z = fmaf(t.z, sc, sum.z); sum.w = fmaf(t.w, sc, sum.w);
+      dsum = fmaf(stat[(w * G + g) * 2 + 1], sc, dsum);
     }
-    const float inv = 1.0f / den;
+    const float inv = 1.0f / dsum;
     const int k = (h * G + g) * 64 + d4;
-    if (p.out) *reinterpret_cast<float4*>(p.out + (long)row * HD + k) = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
-    if (p.out_x3) x3_emit4(p.out_x3, row, k, HD >> 5, s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+    if (p.out) *reinterpret_cast<float4*>(p.out + (long)row * HD + k) = make_float4(sum.x * inv, sum.y * inv, sum.z * inv, sum.w * inv);
+    if (p.out_x3) x3_emit4(p.out_x3, row, k, HD >> 5, sum.x * inv, sum.y * inv, sum.z * inv, sum.w * inv);
   }
 }
 
@@ -261,8 +240,10 @@ int launch_attention(const float* q, const float* kc, const float* vc, const int
   AttnDev d{q, kc, vc, row_pos, row_slot, out, (char*)out_x3, n_q_heads, n_kv_heads, cache_len, window, 0};
   d.score_cap = (window > 0 && window < cache_len) ? window : cache_len;
   d.score_cap = (d.score_cap + 3) & ~3;
-  const int nwaves = d.score_cap <= 64 ? 4 : 16;
-  const size_t lds = ((size_t)G * d.score_cap + 16 * G * 64 + 16 * G + 16) * sizeof(float);
+  // few workgroups (decode: rows x kv heads ~ 128): spread each cache over 16 waves; many rows
+  // (prefill, Mimi): 4 waves per workgroup and let the grid fill the chip
+  const int nwaves = ((long)n_rows * n_kv_heads >= 1024 || d.score_cap <= 64) ? 4 : 16;
+  const size_t lds = ((size_t)16 * G * 64 + 16 * G * 2 + 16) * sizeof(float);
   ST_REQUIRE(lds <= 150 * 1024, SMOLTTS_E_CAPACITY, "attention: %zu bytes of LDS needed for %d keys x %d heads", lds,
              d.score_cap, G);
   ST_REQUIRE(n_kv_heads <= 65535, SMOLTTS_E_INVALID, "attention: grid too large");
