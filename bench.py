@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=8, help="frames per step")
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU-oracle sample (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the first-audio-chunk latency measurement")
     ap.add_argument("--no-mimi", action="store_true", help="diagnostic only: skip the Mimi decode (the result line is then not the metric)")
     ap.add_argument("--overlap-mimi", action="store_true", help="run the Mimi chunk decode on its own stream behind an event (measured: no gain, the many-workgroup Mimi kernels delay the latency-bound frame graphs)")
     ap.add_argument("--streams", type=int, default=1, help="independent decode streams per GPU (slots are split evenly)")
@@ -274,6 +275,40 @@ def main():
         rms = float(np.sqrt(np.mean((pcm[:, : (nF + 1) * 1920].cpu().numpy() - pcm_ref_full) ** 2)))
         parity = {"frames_checked": nF + 1, "ids_bit_identical": bool(same), "pcm_rms_err": rms}
 
+    # ---- first-audio-chunk latency (second half of BASELINE.json's metric): submit -> first 1920 PCM
+    #      samples on the host = prompt prefill + frame 0 + one Mimi step.  (a) this workload: all B
+    #      utterances submitted together; (b) BASELINE configs[1]: smoltts_byte_70m, one utterance.
+    first_chunk = None
+    if rank == 0 and world == 1 and not args.no_latency:
+        def first_chunk_ms(engine, mengine, prompts, reps):
+            ts = []
+            ls = LMSession(engine, max_batch=len(prompts), max_seq=max(p.shape[1] for p in prompts) + 8,
+                           max_rows=sum(p.shape[1] for p in prompts), max_frames=4)
+            ms = MimiSession(mengine, max_batch=len(prompts), max_chunk_frames=1)
+            buf = torch.zeros(len(prompts), 1920, dtype=torch.float32, device=dev)
+            for _ in range(reps + 1):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                ls.prefill(prompts, stop_on_eos=False)
+                ms.reset()
+                ms.decode_chunk(ls.codes, 0, 1, buf, code_offset=1)
+                _ = buf.cpu()
+                ts.append((time.perf_counter() - t1) * 1e3)
+            ms.close(); ls.close()
+            return ts[1:]  # first repetition warms the allocator
+
+        t150 = first_chunk_ms(eng, meng, mine, 5)
+        cfg70 = named_config("smoltts_byte_70m")
+        a70, o70 = pack_lm(cfg70, synthetic_lm_state(cfg70, seed=0), numerics)
+        eng70 = LMEngine(cfg70, None, TokenConfig.from_tokenizer(tok, cfg70), numerics, arena=a70, offsets=o70)
+        t70 = []
+        for u in range(40):
+            t70 += first_chunk_ms(eng70, meng, [all_prompts[u % len(all_prompts)]], 1)
+        first_chunk = {"b32_150m_ms_p50": round(float(np.median(t150)), 2),
+                       "b1_70m_ms_p50": round(float(np.median(t70)), 2), "b1_70m_ms_p95": round(float(np.percentile(t70, 95)), 2),
+                       "b1_70m_prompts": len(t70), "includes": "prefill + frame 0 + Mimi step + D2H copy of 1920 samples"}
+        log(f"first audio chunk: B=32 150m p50 {first_chunk['b32_150m_ms_p50']} ms; B=1 70m p50 {first_chunk['b1_70m_ms_p50']} ms")
+
     if rank == 0:
         out = {
             "metric": "Mimi frames/sec (=12.5 x RTF), greedy DualAR decode + Mimi decode to PCM" + (" [DIAGNOSTIC: Mimi skipped]" if args.no_mimi else ""),
@@ -287,7 +322,7 @@ def main():
             "rtf": round(value / 12.5, 1), "frames_per_s_per_gpu": round(value / world, 1),
             "us_per_frame_step": round(elapsed / (K * CH) * 1e6, 1), "prefill_ms": round(prefill_ms, 2),
             "min_top2_margin": float(margin.min()),
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+            "first_audio_chunk": first_chunk, "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(out), flush=True)
     for x in msessions + sessions:

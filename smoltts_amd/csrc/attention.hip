@@ -38,6 +38,16 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Sum over the 16 lanes of a DPP row, result in every lane: four v_add_f32 with DPP operands
+// (quad xor 1, quad xor 2, half-row mirror, row mirror) instead of four LDS-crossbar shuffles.
+__device__ __forceinline__ float row16_sum(float x) {
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true));  // row_mirror
+  return x;
+}
+
 constexpr int ATT_UN = 8;  // keys per lane group and pass: 8 K + 8 V rows in flight per wave
 
 // Long caches: single pass with an online softmax per lane group (4 groups x nwaves per workgroup, each
@@ -100,10 +110,7 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
         t = fmaf(qv[g].y, kv[u].y, t);
         t = fmaf(qv[g].z, kv[u].z, t);
         t = fmaf(qv[g].w, kv[u].w, t);
-        t += __shfl_xor(t, 1);
-        t += __shfl_xor(t, 2);
-        t += __shfl_xor(t, 4);
-        t += __shfl_xor(t, 8);
+        t = row16_sum(t);
         s[u] = (j0 + u * step < L) ? t : -INFINITY;
         bm = fmaxf(bm, s[u]);
       }
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
 // Caches of at most 16 entries (the depth transformer's per-frame cache, lm/generate.py:112): one wave
 // per (row, kv head), all K/V rows loaded up front, no LDS and no barrier -- the kernel is a single
 // memory round trip plus wave shuffles.
-template <int G>
+template <int G, int UN>
 __global__ __launch_bounds__(256) void attn_short_kernel(AttnDev p, int n_pairs) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int kk = lane >> 4, dl = lane & 15;
@@ -177,9 +184,9 @@ __global__ __launch_bounds__(256) void attn_short_kernel(AttnDev p, int n_pairs)
   const int j_lo = (ok && p.window > 0 && pos + 1 > p.window) ? pos + 1 - p.window : 0;
   const int L = ok ? pos + 1 - j_lo : 0;
   const long cbase = (((long)slot * p.n_kv_heads + h) * p.cache_len + j_lo) * 64;
-  float4 kv[4], vv[4], qv[G];
+  float4 kv[UN], vv[UN], qv[G];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < UN; ++u) {
     const int j = u * 4 + kk;
     const bool v = j < L;
     kv[u] = v ? *reinterpret_cast<const float4*>(p.kc + cbase + (long)j * 64 + dl * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -192,18 +199,15 @@ __global__ __launch_bounds__(256) void attn_short_kernel(AttnDev p, int n_pairs)
   }
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    float s[4];
+    float s[UN];
     float mx = -INFINITY;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UN; ++u) {
       float t = qv[g].x * kv[u].x;
       t = fmaf(qv[g].y, kv[u].y, t);
       t = fmaf(qv[g].z, kv[u].z, t);
       t = fmaf(qv[g].w, kv[u].w, t);
-      t += __shfl_xor(t, 1);
-      t += __shfl_xor(t, 2);
-      t += __shfl_xor(t, 4);
-      t += __shfl_xor(t, 8);
+      t = row16_sum(t);
       s[u] = t;
       if (u * 4 + kk < L) mx = fmaxf(mx, t);
     }
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(256) void attn_short_kernel(AttnDev p, int n_pairs)
     float den = 0.f;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UN; ++u) {
       const float e = (u * 4 + kk < L) ? expf(s[u] - mx) : 0.f;
       den += e;
       a.x = fmaf(e, vv[u].x, a.x); a.y = fmaf(e, vv[u].y, a.y); a.z = fmaf(e, vv[u].z, a.z); a.w = fmaf(e, vv[u].w, a.w);
@@ -250,11 +254,17 @@ int launch_attention(const float* q, const float* kc, const float* vc, const int
   if (cache_len <= 16) {
     const int n_pairs = n_rows * n_kv_heads;
     const dim3 sgrid((n_pairs + 3) / 4);
+#define ST_SHORT(GG)                                                                                       \
+  case GG:                                                                                                 \
+    if (cache_len <= 8) hipLaunchKernelGGL((attn_short_kernel<GG, 2>), sgrid, dim3(256), 0, stream, d, n_pairs); \
+    else hipLaunchKernelGGL((attn_short_kernel<GG, 4>), sgrid, dim3(256), 0, stream, d, n_pairs);           \
+    break;
     switch (G) {
-      case 1: hipLaunchKernelGGL(attn_short_kernel<1>, sgrid, dim3(256), 0, stream, d, n_pairs); break;
-      case 2: hipLaunchKernelGGL(attn_short_kernel<2>, sgrid, dim3(256), 0, stream, d, n_pairs); break;
-      case 3: hipLaunchKernelGGL(attn_short_kernel<3>, sgrid, dim3(256), 0, stream, d, n_pairs); break;
-      case 4: hipLaunchKernelGGL(attn_short_kernel<4>, sgrid, dim3(256), 0, stream, d, n_pairs); break;
+      ST_SHORT(1)
+      ST_SHORT(2)
+      ST_SHORT(3)
+      ST_SHORT(4)
+#undef ST_SHORT
       default:
         set_error("attention: GQA group size %d not instantiated (1..4)", G);
         return SMOLTTS_E_INVALID;
