@@ -231,9 +231,13 @@ def main():
         # algorithmic bytes of one launch: bf16 w1|w3 tiles + X3 operand in (6 B/elem) + X3 h out + partial sums of squares
         bytes_alg = 2 * cfg.intermediate_size * cfg.dim * 2 + Bs * cfg.dim * 6 + Bs * cfg.intermediate_size * 6 + Bs * (cfg.dim // 16) * 4
         ach = bytes_alg / (avg_us * 1e-6) / 1e9
+        traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
+        pmc = ROOT / "profiles" / "r01_pmc_w13.json"
+        if pmc.exists() and args.model == "smoltts_byte_150m" and Bs == 32:
+            traffic = json.loads(pmc.read_text())["hbm_bytes_per_launch"]
         roofline = {"bound": "hbm", "kernel": "gemm3_kernel<MT=2,T=2,U=3,SwiGLU> (RMSNorm-scaled w1|w3 GEMM + SwiGLU)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": None, "avg_us": round(avg_us, 3), "launches_timed": 8 * n_per_frame * 3,
+                    "traffic": traffic, "avg_us": round(avg_us, 3), "launches_timed": 8 * n_per_frame * 3,
                     "bytes_per_launch": bytes_alg, "method": "graph replay with duplicated launches, HIP events"}
 
     # ---- CPU baseline: the oracle (fp32 torch eager) on the same weights/prompts, bounded sample
