@@ -138,6 +138,12 @@ int smoltts_lm_prefill(SmolttsSession* s, const int32_t* grid_dev, const int32_t
  * are done (emitted <|im_end|> with stop_on_eos, or reached max_frames) are frozen. */
 int smoltts_lm_decode(SmolttsSession* s, int32_t n_frames, void* stream);
 
+/* Sampling mode (reference GenerationSettings, lm/generate.py:12-16): temp / fast_temp <= 0 select
+ * greedy argmax for the slow / depth tokens (the default), otherwise exact categorical sampling from
+ * softmax(logits / temp) with a counter-based generator keyed by (seed, slot, frame, step); min_p > 0
+ * keeps only tokens with p >= min_p * p_max (applied to the depth tokens only when fast_temp > 0). */
+int smoltts_session_set_sampling(SmolttsSession* s, float temp, float fast_temp, float min_p, uint64_t seed);
+
 /* Device pointers to the session's results (valid for the session's lifetime):
  *   codes      int32 [max_batch][max_frames][1 + n_fast]   emitted columns (slow id, codes)
  *   n_frames   int32 [max_batch]                            frames emitted so far per slot
@@ -322,6 +328,10 @@ int smoltts_k_embed(const int32_t* cols_dev, int32_t n_rows, int32_t n_code_rows
 /* ids[r] = first index of the row maximum; margin[r] = min(margin[r], top1 - top2). */
 int smoltts_k_argmax(const float* logits_dev, int32_t n_rows, int32_t n_cols, int64_t ld,
                      int32_t* ids_dev, int32_t ids_stride, float* margin_dev, void* stream);
+
+/* ids[r] ~ softmax(logits[r] / temp) (min_p as above); row r uses the stream (seed, r, frame_base + r, step). */
+int smoltts_k_sample(const float* logits_dev, int32_t n_rows, int32_t n_cols, int64_t ld, float temp, float min_p,
+                     uint64_t seed, int32_t frame_base, int32_t step, int32_t* ids_dev, void* stream);
 
 int smoltts_k_layernorm(const float* x_dev, const float* w_dev, const float* b_dev, int32_t n_rows,
                         int32_t dim, float eps, float* out_dev, void* stream);

@@ -53,7 +53,8 @@ class SmolTTS:
     def _settings(self, generation_settings):
         from .config import GenerationSettings
 
-        return generation_settings or GenerationSettings.greedy()
+        # the reference façade always uses GenerationSettings() (temp 0.7 / 0.7, __init__.py:77,85)
+        return generation_settings or GenerationSettings()
 
     def generate_codes(self, inputs: List[str], voices: Optional[List[str]] = None, generation_settings=None):
         """Batched synthesis to audio-code grids: one (n_codebooks, F_b) uint32 array per input."""

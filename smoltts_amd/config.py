@@ -171,6 +171,7 @@ class GenerationSettings:
     default_fast_temp: Optional[float] = 0.7
     min_p: Optional[float] = None
     max_new_tokens: int = 1024
+    seed: Optional[int] = None  # extension: None draws a fresh seed per generator
 
     @classmethod
     def greedy(cls, max_new_tokens: int = 1024) -> "GenerationSettings":

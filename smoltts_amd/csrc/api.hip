@@ -44,6 +44,13 @@ int smoltts_k_embed(const int32_t* cols_dev, int32_t n_rows, int32_t n_code_rows
 int smoltts_k_argmax(const float* logits_dev, int32_t n_rows, int32_t n_cols, int64_t ld, int32_t* ids_dev, int32_t ids_stride,
                      float* margin_dev, void* stream) {
   return launch_argmax(logits_dev, n_rows, n_cols, ld, ids_dev, ids_stride, margin_dev, nullptr, nullptr, 0, 0, nullptr, nullptr,
+                       nullptr, (hipStream_t)stream);
+}
+
+int smoltts_k_sample(const float* logits_dev, int32_t n_rows, int32_t n_cols, int64_t ld, float temp, float min_p, uint64_t seed,
+                     int32_t frame_base, int32_t step, int32_t* ids_dev, void* stream) {
+  const SampleArgs sa{temp, min_p, seed, step, frame_base, nullptr};
+  return launch_argmax(logits_dev, n_rows, n_cols, ld, ids_dev, 1, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, &sa,
                        (hipStream_t)stream);
 }
 

@@ -52,6 +52,17 @@ struct EmitArgs {
   float* ssq;
 };
 
+// Sampling of one row of logits (temp <= 0: greedy). The random stream is a pure function of
+// (seed, row, frame, step, column); frame = frames[row] when given, else frame_base + row.
+struct SampleArgs {
+  float temp;
+  float min_p;
+  uint64_t seed;
+  int step;
+  int frame_base;
+  const int32_t* frames;
+};
+
 // Launchers implemented across the .hip files (all asynchronous on `stream`).
 int launch_gemm(const SmolttsGemmArgs& a, hipStream_t stream);
 int launch_gemm3(const SmolttsGemm3Args& a, hipStream_t stream);
@@ -68,7 +79,8 @@ int launch_embed(const int32_t* cols, int n_rows, int n_code_rows, const void* t
 // emb[(id + emb_row_offset)] (bf16 row-major, `dim` wide) into xnext[r].
 int launch_argmax(const float* logits, int n_rows, int n_cols, int64_t ld, int32_t* ids,
                   int ids_stride, float* margin, const int32_t* margin_mask, const void* emb,
-                  int emb_row_offset, int dim, float* xnext, const EmitArgs* emit, hipStream_t stream);
+                  int emb_row_offset, int dim, float* xnext, const EmitArgs* emit, const SampleArgs* sample,
+                  hipStream_t stream);
 int launch_layernorm(const float* x, const float* w, const float* b, int n_rows, int dim, float eps,
                      float* out, hipStream_t stream);
 int launch_gather_rows(const float* src, const int32_t* idx, int n, int dim, float* dst,

@@ -33,6 +33,8 @@ struct SmolttsSession {
   SmolttsEngine* e;
   int B, max_seq, max_rows, max_frames;
   int stop_on_eos;
+  float temp, fast_temp, min_p;  // <= 0: greedy (lm/generate.py:88-99,118-132)
+  uint64_t seed;
   // activations
   float *xr, *qr;            // prefill rows: fp32 residual stream [max_rows][dim], q [max_rows][Hq*64]
   float *xt, *xf;            // decode/tail rows: [B][dim], [B][fast_dim]
@@ -238,8 +240,9 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
     a.ssq_in_dev = s->ssq; a.eps = c.norm_eps; a.out_dev = s->logits; a.ldo = c.vocab_size;
     ST_TRY(launch_gemm3(a, st));
   }
+  const SampleArgs slow_sa{s->temp, s->min_p, s->seed, 0, 0, s->frames};
   ST_TRY(launch_argmax(s->logits, B, c.vocab_size, c.vocab_size, s->new_col, H, s->margin, s->mask, nullptr, 0, 0, nullptr,
-                       nullptr, st));
+                       nullptr, &slow_sa, st));
   float* xf = s->xt;  // fast input = pre-norm slow hidden (lm/rq_transformer.py:191)
   const char* first_x3 = s->x3n2;
   const EmitArgs to_fast0{s->x3n, gamma_at(e, e->w.fast_layers[0].attn_norm), nullptr, nullptr, s->ssq};
@@ -270,9 +273,10 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
     const bool more = i + 1 < c.n_fast;
     const int off = c.depthwise_wte ? (c.duplicate_code_0 ? i : i + 1) * c.codebook_size : 0;  // generate.py:136-140
     float* xnext = c.has_fast_project_in ? s->xf : s->xt;
+    const SampleArgs fast_sa{s->fast_temp, s->fast_temp > 0.f ? s->min_p : 0.f, s->seed, 1 + i, 0, s->frames};
     ST_TRY(launch_argmax(s->logits, B, c.codebook_size, c.codebook_size, s->new_col + 1 + i, H, s->margin, s->mask,
                          more ? (const void*)(A + e->w.fast_emb) : nullptr, off, c.fast_dim, more ? xnext : nullptr,
-                         more ? &to_fast0 : nullptr, st));
+                         more ? &to_fast0 : nullptr, &fast_sa, st));
     xf = xnext;
   }
   hipLaunchKernelGGL(commit_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, H, s->max_frames, c.im_end_id, s->stop_on_eos,
@@ -499,6 +503,20 @@ int smoltts_lm_decode(SmolttsSession* s, int32_t n_frames, void* stream) {
     s->graph_ready = true;
   }
   for (int f = 0; f < n_frames; ++f) ST_CHECK_HIP(hipGraphLaunch(s->graph_exec, st));
+  return SMOLTTS_OK;
+}
+
+// Sampling mode of the session (reference GenerationSettings, lm/generate.py:12-16): temp / fast_temp <= 0
+// select greedy argmax for the slow / depth tokens; min_p <= 0 disables the filter.  Takes effect from
+// the next frame (the captured graph is dropped).
+int smoltts_session_set_sampling(SmolttsSession* s, float temp, float fast_temp, float min_p, uint64_t seed) {
+  ST_REQUIRE(s, SMOLTTS_E_INVALID, "session_set_sampling: null session");
+  ST_REQUIRE(min_p < 1.0f, SMOLTTS_E_INVALID, "session_set_sampling: min_p must be < 1");
+  s->temp = temp; s->fast_temp = fast_temp; s->min_p = min_p; s->seed = seed;
+  if (s->graph_ready) {
+    (void)hipGraphExecDestroy(s->graph_exec);
+    s->graph_ready = false;
+  }
   return SMOLTTS_OK;
 }
 

@@ -73,10 +73,29 @@ __device__ __forceinline__ Top2 top2_merge(Top2 a, Top2 b) {
   return o;
 }
 
+// Counter-based uniform in (0, 1): a function of (seed, slot, frame, step, column) only, so sampling is
+// reproducible under graph replay and independent of launch geometry.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float uniform01(uint64_t seed, int slot, int frame, int step, int col) {
+  uint32_t h = mix32((uint32_t)seed ^ 0x9E3779B9U * (uint32_t)(slot + 1));
+  h = mix32(h ^ (uint32_t)(seed >> 32) ^ 0x85EBCA6BU * (uint32_t)(frame + 1));
+  h = mix32(h ^ 0xC2B2AE35U * (uint32_t)(step + 1));
+  h = mix32(h ^ 0x27D4EB2FU * (uint32_t)(col + 1));
+  return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+// Greedy: first index of the row maximum (torch.argmax / mx.argmax).  Sampling (temp > 0): exact
+// categorical sampling from softmax(logits / temp) by the Gumbel-max trick, optionally restricted to
+// tokens with p >= min_p * p_max (the intent of lm/utils/samplers.py:8-34; as written there the
+// threshold is compared with the token's own value and never removes anything).
 __global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int n_cols, long ld, int* ids, int ids_stride,
                                                      float* margin, const int* margin_mask, const uint16_t* emb,
-                                                     int emb_row_offset, int dim, float* xnext, EmitDev emit) {
+                                                     int emb_row_offset, int dim, float* xnext, EmitDev emit, SampleArgs sa) {
   __shared__ Top2 sh[4];
+  __shared__ Top2 sh2[4];
   __shared__ float sh4[4];
   __shared__ int s_id;
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -98,11 +117,35 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int n_
   }
   if (lane == 0) sh[wave] = t;
   __syncthreads();
+  Top2 a = top2_merge(top2_merge(sh[0], sh[1]), top2_merge(sh[2], sh[3]));
+  if (sa.temp > 0.f) {  // uniform: second pass over the row with perturbed keys
+    const int frame = sa.frames ? sa.frames[r] : sa.frame_base + r;
+    const float inv_t = 1.0f / sa.temp;
+    const float cut = sa.min_p > 0.f ? logf(sa.min_p) : -INFINITY;
+    Top2 k{-INFINITY, 0x7fffffff, -INFINITY};
+    for (int j = tid; j < n_cols; j += 256) {
+      const float z = (row[j] - a.v1) * inv_t;  // <= 0
+      if (z >= cut) {
+        const float u = uniform01(sa.seed, r, frame, sa.step, j);
+        const float key = z - logf(-logf(u));
+        if (key > k.v1) { k.v1 = key; k.i1 = j; }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      Top2 b;
+      b.v1 = __shfl_xor(k.v1, o); b.i1 = __shfl_xor(k.i1, o); b.v2 = -INFINITY;
+      k = top2_merge(k, b);
+    }
+    if (lane == 0) sh2[wave] = k;
+    __syncthreads();
+    const Top2 w = top2_merge(top2_merge(sh2[0], sh2[1]), top2_merge(sh2[2], sh2[3]));
+    a.i1 = w.i1;
+  }
   if (tid == 0) {
-    Top2 a = top2_merge(top2_merge(sh[0], sh[1]), top2_merge(sh[2], sh[3]));
     if (a.i1 < 0 || a.i1 >= n_cols) a.i1 = 0;  // all-NaN row: stay inside the tables
     ids[(long)r * ids_stride] = a.i1;
-    if (margin && (margin_mask == nullptr || margin_mask[r])) margin[r] = fminf(margin[r], a.v1 - a.v2);
+    if (sa.temp <= 0.f && margin && (margin_mask == nullptr || margin_mask[r])) margin[r] = fminf(margin[r], a.v1 - a.v2);
     s_id = a.i1;
   }
   if (emb == nullptr) return;
@@ -121,13 +164,15 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int n_
 
 int launch_argmax(const float* logits, int n_rows, int n_cols, int64_t ld, int32_t* ids, int ids_stride, float* margin,
                   const int32_t* margin_mask, const void* emb, int emb_row_offset, int dim, float* xnext,
-                  const EmitArgs* emit, hipStream_t stream) {
+                  const EmitArgs* emit, const SampleArgs* sample, hipStream_t stream) {
+  SampleArgs sa{0.f, 0.f, 0, 0, 0, nullptr};
+  if (sample) sa = *sample;
   EmitDev e{nullptr, nullptr, nullptr, nullptr, nullptr};
   if (emit && emb) e = EmitDev{(char*)emit->x3a, emit->gamma_a, (char*)emit->x3b, emit->gamma_b, emit->ssq};
   ST_REQUIRE(logits && ids && n_rows > 0 && n_cols > 0, SMOLTTS_E_INVALID, "argmax: bad arguments");
   ST_REQUIRE(emb == nullptr || (xnext && dim % 4 == 0), SMOLTTS_E_INVALID, "argmax: bad gather arguments");
   hipLaunchKernelGGL(argmax_kernel, dim3(n_rows), dim3(256), 0, stream, logits, n_cols, (long)ld, ids, ids_stride, margin,
-                     margin_mask, (const uint16_t*)emb, emb_row_offset, dim, xnext, e);
+                     margin_mask, (const uint16_t*)emb, emb_row_offset, dim, xnext, e, sa);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
 }

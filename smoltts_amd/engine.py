@@ -87,7 +87,7 @@ _EXPORTS = [
     "smoltts_mimi_slab_bytes", "smoltts_mimi_session_create", "smoltts_mimi_session_destroy", "smoltts_mimi_reset",
     "smoltts_mimi_decode_chunk", "smoltts_k_gemm", "smoltts_k_attention", "smoltts_k_embed", "smoltts_k_argmax",
     "smoltts_k_layernorm", "smoltts_profile_begin", "smoltts_profile_end", "smoltts_k_gemm3", "smoltts_k_x3_pack",
-    "smoltts_debug_duplicate", "smoltts_session_drop_graph",
+    "smoltts_debug_duplicate", "smoltts_session_drop_graph", "smoltts_session_set_sampling", "smoltts_k_sample",
 ]
 
 
@@ -133,6 +133,9 @@ def load_library(path: Optional[Path] = None):
     lib.smoltts_k_embed.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]
     lib.smoltts_k_argmax.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.smoltts_k_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
+    lib.smoltts_session_set_sampling.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_uint64]
+    lib.smoltts_k_sample.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_uint64, C.c_int32,
+                                     C.c_int32, C.c_void_p, C.c_void_p]
     lib.smoltts_debug_duplicate.argtypes = [C.c_int32, C.c_int32]
     lib.smoltts_session_drop_graph.argtypes = [C.c_void_p]
     lib.smoltts_profile_begin.argtypes = [C.c_int32] * 4
@@ -309,6 +312,11 @@ class LMSession:
         self._keep = (grid_d, rslot_d, rpos_d)  # alive until the stream has consumed them
         check(self.lib.smoltts_lm_prefill(self.handle, dptr(grid_d), dptr(rslot_d), dptr(rpos_d), n, slots_h, last_h,
                                           len(slots), int(stop_on_eos), current_stream_ptr()), "smoltts_lm_prefill")
+
+    def set_sampling(self, temp: float = 0.0, fast_temp: float = 0.0, min_p: float = 0.0, seed: int = 0) -> None:
+        """temp / fast_temp <= 0: greedy (default). Takes effect from the next frame."""
+        check(self.lib.smoltts_session_set_sampling(self.handle, float(temp), float(fast_temp), float(min_p), int(seed) & (2**64 - 1)),
+              "smoltts_session_set_sampling")
 
     def decode(self, n_frames: int) -> None:
         check(self.lib.smoltts_lm_decode(self.handle, int(n_frames), current_stream_ptr()), "smoltts_lm_decode")

@@ -7,8 +7,11 @@ device nine times per frame; here the frame loop (slow step, 8 depth steps, argm
 stop rule) runs on the GPU inside ``smoltts_lm_decode`` and the host only fetches finished columns.
 ``BatchGenerator`` is the same loop for B utterances at once.
 
-Greedy decoding only in this round (``default_temp == 0`` and no fast temperature): the sampled
-modes of the reference (temperature / min_p, lm/utils/samplers.py) are listed as next in DESIGN.md.
+Sampling follows the reference's rules (lm/generate.py:88-99,118-132): the slow token is greedy iff
+``default_temp == 0``; the depth tokens are sampled iff ``default_fast_temp`` is set and > 0; ``min_p``
+(lm/utils/samplers.py:8-34) restricts the candidates.  It runs on the device with a counter-based
+generator keyed by ``GenerationSettings.seed`` (reproducible for a fixed seed; the reference's MLX
+generator is not reproducible across processes, so parity for the sampled modes is statistical).
 """
 from __future__ import annotations
 
@@ -28,11 +31,14 @@ class VQToken:
     vq_tensor: Any              # (1, 1 + n_fast, 1) uint32
 
 
-def _require_greedy(settings: GenerationSettings) -> None:
-    if not settings.is_greedy:
-        raise NotImplementedError(
-            "smoltts_amd decodes greedily on the device; pass GenerationSettings.greedy() "
-            "(default_temp=0.0, default_fast_temp=0.0). Temperature/min_p sampling is not built yet.")
+def _apply_sampling(session: LMSession, settings: GenerationSettings) -> None:
+    fast = settings.default_fast_temp if settings.default_fast_temp is not None else 0.0
+    seed = settings.seed
+    if seed is None:
+        import os
+
+        seed = int.from_bytes(os.urandom(8), "little")
+    session.set_sampling(temp=settings.default_temp, fast_temp=max(fast, 0.0), min_p=settings.min_p or 0.0, seed=seed)
 
 
 def _frame_to_token(engine: LMEngine, col: np.ndarray) -> VQToken:
@@ -53,7 +59,6 @@ class BatchGenerator:
 
     def __init__(self, engine: LMEngine, prompts: Sequence[np.ndarray], generation_settings: GenerationSettings,
                  audio_only: bool = True, frames_per_sync: int = 1, session: Optional[LMSession] = None):
-        _require_greedy(generation_settings)
         self.engine = engine
         self.settings = generation_settings
         self.audio_only = audio_only
@@ -63,6 +68,7 @@ class BatchGenerator:
         max_T = max(int(p.shape[1]) for p in prompts)
         self.session = session or LMSession(engine, self.B, max_seq=min(engine.cfg.max_seq_len, max_T + self.max_frames + 1),
                                             max_rows=sum(int(p.shape[1]) for p in prompts), max_frames=self.max_frames)
+        _apply_sampling(self.session, generation_settings)
         self._prompts = list(prompts)
         self._started = False
         self._emitted = np.zeros(self.B, dtype=np.int64)

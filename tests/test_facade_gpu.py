@@ -79,5 +79,11 @@ def test_generate_blocking_and_pth_checkpoint(setup):
         assert (f.audio_codes is not None) == sem
         if sem:
             assert f.audio_codes.shape == (1, 8, 1) and f.audio_codes[0, :, 0].tolist() == col[1:].tolist()
-    with pytest.raises(NotImplementedError):
-        generate_blocking(tts.lm, prompt, GenerationSettings())  # reference default temp 0.7: sampling is not built
+    # reference defaults (temp 0.7 / 0.7): sampled on the device, reproducible per seed
+    s1 = generate_blocking(tts.lm, prompt, GenerationSettings(max_new_tokens=7, seed=5), audio_only=False)
+    s2 = generate_blocking(tts.lm, prompt, GenerationSettings(max_new_tokens=7, seed=5), audio_only=False)
+    s3 = generate_blocking(tts.lm, prompt, GenerationSettings(max_new_tokens=7, seed=6), audio_only=False)
+    assert np.array_equal(s1, s2) and not np.array_equal(s1, s3) and not np.array_equal(s1, a)
+    # slow sampled, depth greedy (the server's defaults: temp 0.5, fast temp 0.0)
+    s4 = generate_blocking(tts.lm, prompt, GenerationSettings(default_temp=0.5, default_fast_temp=0.0, min_p=0.1, max_new_tokens=7, seed=1), audio_only=False)
+    assert s4.shape == (1, 9, 8)

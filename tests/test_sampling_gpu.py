@@ -1,0 +1,89 @@
+"""Sampling parity is statistical (the reference's MLX generator is not reproducible): the device
+sampler must draw from softmax(logits / temp), restricted by min_p, and be a pure function of its key."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _sample(logits_row, n, temp, min_p, seed, frame_base=0, step=0):
+    from smoltts_amd import engine as E
+
+    lib = E.load_library()
+    logits = logits_row[None].repeat(n, 1).contiguous().cuda()
+    ids = torch.empty(n, dtype=torch.int32, device="cuda")
+    E.check(lib.smoltts_k_sample(E.dptr(logits), n, logits.shape[1], logits.stride(0), temp, min_p, seed, frame_base, step,
+                                 E.dptr(ids), E.current_stream_ptr()), "smoltts_k_sample")
+    return ids.cpu().numpy()
+
+
+def _chi2_ok(counts, probs, n):
+    keep = probs * n >= 5
+    exp = probs[keep] * n
+    chi2 = float(((counts[keep] - exp) ** 2 / exp).sum())
+    dof = int(keep.sum()) - 1
+    return chi2 < dof + 6 * math.sqrt(2 * dof), chi2, dof  # ~6 sigma
+
+
+@pytest.mark.parametrize("temp,min_p", [(1.0, 0.0), (0.7, 0.0), (0.5, 0.1)])
+def test_sampler_follows_softmax(temp, min_p):
+    g = torch.Generator().manual_seed(3)
+    V = 2368
+    row = torch.randn(V, generator=g) * 2.0
+    n = 60000
+    ids = _sample(row, n, temp, min_p, seed=12345)
+    z = (row - row.max()) / temp
+    if min_p > 0:
+        z = torch.where(z >= math.log(min_p), z, torch.full_like(z, float("-inf")))
+        assert set(np.unique(ids)).issubset(set(torch.nonzero(torch.isfinite(z)).flatten().tolist()))
+    probs = torch.softmax(z.double(), dim=0).numpy()
+    counts = np.bincount(ids, minlength=V).astype(np.float64)
+    ok, chi2, dof = _chi2_ok(counts, probs, n)
+    assert ok, f"chi2 {chi2:.1f} for {dof} dof"
+
+
+def test_sampler_is_a_pure_function_of_its_key():
+    row = torch.randn(2048, generator=torch.Generator().manual_seed(1))
+    a = _sample(row, 256, 0.7, 0.0, seed=7, frame_base=3, step=2)
+    assert np.array_equal(a, _sample(row, 256, 0.7, 0.0, seed=7, frame_base=3, step=2))
+    for kw in (dict(seed=8, frame_base=3, step=2), dict(seed=7, frame_base=4, step=2), dict(seed=7, frame_base=3, step=3)):
+        assert not np.array_equal(a, _sample(row, 256, 0.7, 0.0, **kw))
+    # frame_base + row is the frame counter: shifting the base shifts the draws along the rows
+    b = _sample(row, 256, 0.7, 0.0, seed=7, frame_base=4, step=2)
+    assert len(np.unique(a)) > 20 and not np.array_equal(a[1:], b[:-1])  # the row index is part of the key too
+
+
+def test_session_sampling_modes_and_greedy_limit():
+    from smoltts_amd.config import TokenConfig
+    from smoltts_amd.engine import LMEngine, LMSession
+    from smoltts_amd.prompt import PromptEncoder
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+    from smoltts_amd.tokenizer import load_tokenizer
+
+    cfg = named_config("tiny")
+    tok = load_tokenizer()
+    eng = LMEngine(cfg, synthetic_lm_state(cfg, seed=2), TokenConfig.from_tokenizer(tok, cfg))
+    pe = PromptEncoder(tok, 320)
+    prompts = [pe.build_prompt("sampling modes", "heart"), pe.build_prompt("b", "sky")]
+
+    def run(**kw):
+        s = LMSession(eng, 2, max_seq=128, max_rows=128, max_frames=8)
+        s.set_sampling(**kw)
+        s.prefill(prompts, stop_on_eos=False)
+        s.decode(7)
+        out = s.fetch()[0].copy()
+        s.close()
+        return out
+
+    greedy = run()
+    assert np.array_equal(greedy, run(temp=1e-8, fast_temp=1e-8, seed=3))       # temperature -> 0 is greedy (the depth logits are O(1e-2))
+    slow_only = run(temp=1.5, fast_temp=0.0, seed=3)
+    assert np.array_equal(slow_only, run(temp=1.5, fast_temp=0.0, seed=3))     # replayable
+    assert not np.array_equal(slow_only[:, :, 0], greedy[:, :, 0])            # slow ids are sampled
+    both = run(temp=1.5, fast_temp=1.5, seed=3)
+    assert np.array_equal(both[:, 0, 0], slow_only[:, 0, 0])                  # same key => same first slow draw
+    assert not np.array_equal(both[:, :, 1:], slow_only[:, :, 1:])
