@@ -22,9 +22,10 @@ from .wav import pcm_to_wav_bytes
 
 
 class TTSCore:
-    def __init__(self, model, settings=None):
+    def __init__(self, model, settings=None, scheduler=None):
         self.model = model
         self.settings = settings
+        self.scheduler = scheduler  # BatchScheduler: concurrent requests share the GPU batch
 
     def resolve_speaker_id(self, voice: Union[str, int]) -> int:
         if isinstance(voice, int):
@@ -34,11 +35,16 @@ class TTSCore:
         return 0
 
     def generate_audio(self, input_text: str, voice: Union[str, int], response_format: str = "wav_24000"):
-        pcm = np.asarray(self.model(input_text, str(voice))).flatten()
+        if self.scheduler is not None:
+            pcm = self.scheduler.synthesize(input_text, str(voice))
+        else:
+            pcm = np.asarray(self.model(input_text, str(voice))).flatten()
         return self.format_audio_chunk(pcm, response_format)
 
     def stream_audio(self, input_text: str, voice: Union[str, int]):
-        for chunk in self.model.stream(input_text, str(voice)):
+        chunks = (self.scheduler.iter_chunks(self.scheduler.submit(input_text, str(voice), stream=True))
+                  if self.scheduler is not None else self.model.stream(input_text, str(voice)))
+        for chunk in chunks:
             if chunk is not None:
                 yield np.asarray(chunk, dtype=np.float32).tobytes()
 
@@ -73,14 +79,14 @@ eleven_router = APIRouter(prefix="/v1", tags=["ElevenLabs"])
 
 
 @openai_router.post("/audio/speech")
-async def openai_speech(item: SpeechRequest, http_request: Request):
+def openai_speech(item: SpeechRequest, http_request: Request):
     core = http_request.app.state.tts_core
     audio, media_type = core.generate_audio(item.input, item.voice, item.response_format + "_24000")
     return Response(audio, media_type=media_type, headers={"Content-Disposition": 'attachment; filename="speech.wav"'})
 
 
 @eleven_router.post("/text-to-speech/{voice_id}")
-async def text_to_speech_blocking(voice_id: str, item: CreateSpeechRequest, http_request: Request,
+def text_to_speech_blocking(voice_id: str, item: CreateSpeechRequest, http_request: Request,
                                   output_format: Optional[str] = Query(None, description="pcm_24000 | wav_24000")):
     core = http_request.app.state.tts_core
     fmt = output_format or "wav_24000"
@@ -91,20 +97,22 @@ async def text_to_speech_blocking(voice_id: str, item: CreateSpeechRequest, http
 
 
 @eleven_router.post("/text-to-speech/{voice_id}/stream")
-async def stream_tts(voice_id: str, item: CreateSpeechRequest, http_request: Request,
+def stream_tts(voice_id: str, item: CreateSpeechRequest, http_request: Request,
                      output_format: Literal["pcm_24000"] = "pcm_24000"):
     core = http_request.app.state.tts_core
     return StreamingResponse(core.stream_audio(item.text, voice=voice_id), media_type="audio/wav", headers={
         "Content-Disposition": 'attachment; filename="speech.pcm"', "X-Sample-Rate": "24000"})
 
 
-def create_app(model=None, settings: Optional[dict] = None) -> FastAPI:
-    """``model``: a ``smoltts_amd.SmolTTS`` (or any object with ``__call__``/``stream``)."""
+def create_app(model=None, settings: Optional[dict] = None, scheduler=None) -> FastAPI:
+    """``model``: a ``smoltts_amd.SmolTTS`` (or any object with ``__call__``/``stream``); ``scheduler``: an
+    optional ``BatchScheduler`` so that concurrent requests are decoded together (handlers are plain
+    ``def`` and run in FastAPI's thread pool; the reference's ``async def`` handlers serialise requests)."""
     app = FastAPI()
     app.include_router(openai_router)
     app.include_router(eleven_router)
     app.state.settings = settings
-    app.state.tts_core = TTSCore(model, settings)
+    app.state.tts_core = TTSCore(model, settings, scheduler)
     return app
 
 
@@ -120,8 +128,15 @@ def main():
     settings = json.loads(open(args.config).read()) if args.config else {}
     if not settings.get("checkpoint_dir"):
         raise SystemExit("settings must name checkpoint_dir (model_id downloads need network access)")
+    from ..config import GenerationSettings
+    from .scheduler import BatchScheduler
+
     model = SmolTTS(checkpoint_dir=settings["checkpoint_dir"], mimi_checkpoint=settings.get("mimi_checkpoint"))
-    uvicorn.run(create_app(model, settings), host="0.0.0.0", port=args.port)
+    gen = settings.get("generation") or {}
+    gs = GenerationSettings(default_temp=gen.get("default_temp", 0.5), default_fast_temp=gen.get("default_fast_temp", 0.0),
+                            min_p=gen.get("min_p", 0.1), max_new_tokens=gen.get("max_new_tokens", 1024))  # server/settings.py:33-38
+    sched = BatchScheduler(model, max_batch=int(settings.get("max_batch", 32)), generation_settings=gs)
+    uvicorn.run(create_app(model, settings, sched), host="0.0.0.0", port=args.port)
 
 
 if __name__ == "__main__":
