@@ -30,6 +30,7 @@ struct Gemm3Dev {
   const char* w;
   const char* x3;
   int M, N, K;
+  int half_rows;  // MT == 1 only: a workgroup owns 8 of the tile's 16 rows (twice the workgroups, half the X3 bytes each)
   const float* ssq_in;
   float eps;
   const float* bias;
@@ -63,7 +64,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
   const int nwaves = blockDim.x >> 6;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, q = lane >> 4;
-  const int ng = blockIdx.x, mg = blockIdx.y;
+  const int ng = blockIdx.x;
+  const int mg = p.half_rows ? (blockIdx.y >> 1) : blockIdx.y;
+  const bool row_on = !p.half_rows || ((r >> 3) == (int)(blockIdx.y & 1));  // this lane's row belongs to the workgroup
   const int nchunks = p.K >> 5;
   constexpr bool kResid = EPI == SMOLTTS_EPI_RESID;
   constexpr bool kEmits = EPI == SMOLTTS_EPI_RESID || EPI == SMOLTTS_EPI_STORE;
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
 
   const bool fin = wave < MT;  // waves that will finish the tiles
   const int m = (mg * MT + wave) * 16 + r;  // meaningful for fin waves only
-  const bool mvalid = fin && m < p.M;
+  const bool mvalid = fin && m < p.M && row_on;
 
   f32x4 acc[T][MT];
   const char* xb[MT];
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int mtile = mg * MT + mt;
-    xv[mt] = mtile * 16 < p.M;
+    xv[mt] = mtile * 16 < p.M && row_on;
     xb[mt] = p.x3 + (size_t)mtile * nchunks * 3072 + lane * 16;
   }
 #pragma unroll
@@ -269,7 +272,7 @@ template <int MT, int T, int U, int EPI>
 static int launch3_one(const Gemm3Dev& d, int nwaves, hipStream_t stream) {
   const int ntiles = (d.N + 15) / 16;
   if (nwaves < MT) nwaves = MT;  // one finishing wave per 16-row tile
-  const dim3 grid((ntiles + T - 1) / T, (d.M + 16 * MT - 1) / (16 * MT));
+  const dim3 grid((ntiles + T - 1) / T, ((d.M + 16 * MT - 1) / (16 * MT)) * (d.half_rows ? 2 : 1));
   const size_t lds = (size_t)nwaves * T * MT * 1024;
   hipLaunchKernelGGL((gemm3_kernel<MT, T, U, EPI>), grid, dim3(nwaves * 64), lds, stream, d);
   ST_CHECK_HIP(hipGetLastError());
@@ -286,15 +289,21 @@ static int launch3_epi(const Gemm3Dev& d, hipStream_t stream) {
   const int cpw = (nchunks + nwaves - 1) / nwaves;  // chunks per wave
   if (d.M > 32)  // prefill: 64 rows per workgroup, weights re-used from registers
     return launch3_one<4, 1, 2, EPI>(d, nwaves < 4 ? 4 : nwaves, stream);
-  const bool two_row_tiles = d.M > 16 && ntiles >= 128;
-  if (two_row_tiles) {
-    if (ntiles >= 320) return launch3_one<2, 2, 3, EPI>(d, nwaves, stream);
-    return launch3_one<2, 1, 3, EPI>(d, nwaves, stream);
-  }
-  if (ntiles >= 512) return launch3_one<1, 2, 3, EPI>(d, nwaves, stream);
-  if (cpw > 6) return launch3_one<1, 1, 12, EPI>(d, nwaves, stream);
-  if (cpw > 3) return launch3_one<1, 1, 6, EPI>(d, nwaves, stream);
-  return launch3_one<1, 1, 3, EPI>(d, nwaves, stream);
+  // 16-row tiles go to separate workgroups (MT = 1); T = the smallest number of column tiles per
+  // workgroup that keeps the grid within one workgroup per CU, so every CU takes the activation
+  // operand in once and the per-CU byte load (the bound of these kernels) is as even as possible.
+  const int row_tiles = (d.M + 15) / 16;
+  int T = 1;
+  while (T < 4 && ((ntiles + T - 1) / T) * row_tiles > 256) ++T;
+  if (T == 4) return launch3_one<1, 4, 3, EPI>(d, nwaves, stream);
+  if (T == 3) return launch3_one<1, 3, 3, EPI>(d, nwaves, stream);
+  if (T == 2) return launch3_one<1, 2, 3, EPI>(d, nwaves, stream);
+  // few column tiles: split the 16-row tiles in two so that ~2x the CUs share the activation bytes
+  Gemm3Dev dd = d;
+  dd.half_rows = (d.M > 8 && ntiles * row_tiles * 2 <= 256) ? 1 : 0;
+  if (cpw > 6) return launch3_one<1, 1, 12, EPI>(dd, nwaves, stream);
+  if (cpw > 3) return launch3_one<1, 1, 6, EPI>(dd, nwaves, stream);
+  return launch3_one<1, 1, 3, EPI>(dd, nwaves, stream);
 }
 
 unsigned long long* debug_stamp_buffer();  // gemm.hip
