@@ -10,7 +10,9 @@
 // The cache is fp32 [slot][kv head][cache_len][64], so a key is 256 contiguous bytes: 16 lanes x
 // float4 read one key and a wave reads 4 keys per instruction (1 KiB, coalesced), four such loads
 // in flight per wave.  Short caches (the 8-entry depth-transformer cache) run 4 waves, long ones 16.
-// Softmax is computed online per lane group and merged in a fixed order (deterministic).
+// Softmax is computed online per lane group and merged in a fixed order (deterministic).  exp() is the
+// hardware exp2 path (__expf): its error is |x| * 2^-24 relative on e^x with x <= 0, i.e. at most 2.2e-8
+// absolute on a softmax weight -- below the fp32 rounding of the weights themselves.
 // The result is written as fp32 rows and/or directly as the X3 operand of the following wo GEMM.
 #include "x3.h"
 
@@ -116,12 +118,12 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
       }
       if (bm > -INFINITY) {  // uniform inside the 16-lane group
         const float mn = fmaxf(mx[g], bm);
-        const float sc = expf(mx[g] - mn);  // exp(-inf) = 0 on the first block
+        const float sc = __expf(mx[g] - mn);  // exp(-inf) = 0 on the first block
         float d = den[g] * sc;
         float4 a = make_float4(acc[g].x * sc, acc[g].y * sc, acc[g].z * sc, acc[g].w * sc);
 #pragma unroll
         for (int u = 0; u < ATT_UN; ++u) {
-          const float e = expf(s[u] - mn);  // masked keys: exp(-inf) = 0
+          const float e = __expf(s[u] - mn);  // masked keys: exp(-inf) = 0
           d += e;
           a.x = fmaf(e, vv[u].x, a.x); a.y = fmaf(e, vv[u].y, a.y); a.z = fmaf(e, vv[u].z, a.z); a.w = fmaf(e, vv[u].w, a.w);
         }
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
       const float om = __shfl_xor(mx[g], o), od = __shfl_xor(den[g], o);
       const float ox = __shfl_xor(acc[g].x, o), oy = __shfl_xor(acc[g].y, o), oz = __shfl_xor(acc[g].z, o), ow = __shfl_xor(acc[g].w, o);
       const float mn = fmaxf(mx[g], om);
-      const float sa = mn > -INFINITY ? expf(mx[g] - mn) : 0.f, sb = mn > -INFINITY ? expf(om - mn) : 0.f;
+      const float sa = mn > -INFINITY ? __expf(mx[g] - mn) : 0.f, sb = mn > -INFINITY ? __expf(om - mn) : 0.f;
       den[g] = den[g] * sa + od * sb;
       acc[g] = make_float4(acc[g].x * sa + ox * sb, acc[g].y * sa + oy * sb, acc[g].z * sa + oz * sb, acc[g].w * sa + ow * sb);
       mx[g] = mn;
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
     float dsum = 0.f;
     for (int w = 0; w < nwaves; ++w) {
       const float wm = stat[(w * G + g) * 2];
-      const float sc = wm > -INFINITY ? expf(wm - gm) : 0.f;
+      const float sc = wm > -INFINITY ? __expf(wm - gm) : 0.f;
       const float4 t = *reinterpret_cast<const float4*>(part + (w * G + g) * 64 + d4);
       sum.x = fmaf(t.x, sc, sum.x); sum.y = fmaf(t.y, sc, sum.y); sum.z = fmaf(t.z, sc, sum.z); sum.w = fmaf(t.w, sc, sum.w);
       dsum = fmaf(stat[(w * G + g) * 2 + 1], sc, dsum);
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256) void attn_short_kernel(AttnDev p, int n_pairs)
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const float e = (u * 4 + kk < L) ? expf(s[u] - mx) : 0.f;
+      const float e = (u * 4 + kk < L) ? __expf(s[u] - mx) : 0.f;
       den += e;
       a.x = fmaf(e, vv[u].x, a.x); a.y = fmaf(e, vv[u].y, a.y); a.z = fmaf(e, vv[u].z, a.z); a.w = fmaf(e, vv[u].w, a.w);
     }
