@@ -68,11 +68,11 @@ def make_prompts(pe, n_total, seed=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="smoltts_byte_150m")
     ap.add_argument("--batch", type=int, default=32, help="utterance slots per GPU")
-    ap.add_argument("--chunk", type=int, default=16, help="frames per step")
+    ap.add_argument("--chunk", type=int, default=32, help="frames per step")
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU-oracle sample (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the first-audio-chunk latency measurement")

@@ -375,6 +375,37 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmDev p, int WN) {
         for (int i = 0; i < 4 && n0 + i < p.N; ++i) p.out[orow + n0 + i] = p.elu_out ? elu1(v[i]) : v[i];
         continue;
       }
+      if (EPI == SMOLTTS_EPI_GELU) {
+        *reinterpret_cast<float4*>(p.out + orow + n0) = make_float4(gelu1(v[0]), gelu1(v[1]), gelu1(v[2]), gelu1(v[3]));
+        continue;
+      }
+      if (EPI == SMOLTTS_EPI_SCALE_RESID) {
+        const float4 rr = *reinterpret_cast<const float4*>(p.resid + row_off(m, p.rows_per_batch, p.ldr, p.r_bstride) + n0);
+        const float4 sc = *reinterpret_cast<const float4*>(p.scale + n0);
+        *reinterpret_cast<float4*>(p.out + orow + n0) =
+            make_float4(rr.x + sc.x * v[0], rr.y + sc.y * v[1], rr.z + sc.z * v[2], rr.w + sc.w * v[3]);
+        continue;
+      }
+      if (EPI == SMOLTTS_EPI_QKV_ROPE) {
+        const int pos = p.row_pos[m], slot = p.row_slot[m];
+        const int qd = p.n_q_heads * 64, kd = p.n_kv_heads * 64;
+        if (n0 < qd + kd) {
+          const float4 cs = *reinterpret_cast<const float4*>(p.rope + ((long)pos * 32 + ((n0 & 63) >> 1)) * 2);
+          const float o0 = v[0] * cs.x - v[1] * cs.y, o1 = v[1] * cs.x + v[0] * cs.y;
+          const float o2 = v[2] * cs.z - v[3] * cs.w, o3 = v[3] * cs.z + v[2] * cs.w;
+          v[0] = o0; v[1] = o1; v[2] = o2; v[3] = o3;
+        }
+        const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (n0 < qd) {
+          *reinterpret_cast<float4*>(p.out + orow + n0) = o;
+        } else if (pos >= 0 && pos < p.cache_len) {
+          const int nn = n0 - qd;
+          float* base = nn < kd ? p.kc : p.vc;
+          const int h = (nn < kd ? nn : nn - kd) >> 6, d = nn & 63;
+          *reinterpret_cast<float4*>(base + (((long)slot * p.n_kv_heads + h) * p.cache_len + pos) * 64 + d) = o;
+        }
+        continue;
+      }
       if (EPI == SMOLTTS_EPI_RESID) {
         const float4 rr = *reinterpret_cast<const float4*>(p.resid + row_off(m, p.rows_per_batch, p.ldr, p.r_bstride) + n0);
         v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
@@ -495,9 +526,26 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
   else
     ST_REQUIRE(a.out_dev, SMOLTTS_E_INVALID, "gemm: null output");
 
-  if (a.w_is_fp32 && P == SMOLTTS_PRO_NONE && a.M >= 1024 && (E == SMOLTTS_EPI_STORE || E == SMOLTTS_EPI_RESID)) {
+  // many rows: the LDS-staged kernel, provided its grid (64*WM rows x 16*NTW*WN columns per workgroup,
+  // K not split) still fills the chip; otherwise the K-split skinny kernel has the shorter critical path
+  long rows_grid = 0;
+  {
+    const int ntiles = (a.N + 15) / 16;
+    const int NTW = ntiles >= 16 ? 4 : (ntiles >= 8 ? 2 : 1);
+    const int per = (ntiles + NTW - 1) / NTW;
+    const int WN = per >= 4 ? 4 : (per >= 2 ? 2 : 1);
+    rows_grid = (long)((per + WN - 1) / WN) * ((a.M + 64 * (4 / WN) - 1) / (64 * (4 / WN)));
+  }
+  if (a.w_is_fp32 && P == SMOLTTS_PRO_NONE && a.M >= 1024 && rows_grid >= 192) {
     ST_REQUIRE((long)((a.M + 63) / 64) <= 65535 * 4L, SMOLTTS_E_INVALID, "gemm: M=%d too large for one launch", a.M);
-    return E == SMOLTTS_EPI_STORE ? launch_rows<SMOLTTS_EPI_STORE>(d, stream) : launch_rows<SMOLTTS_EPI_RESID>(d, stream);
+    switch (E) {
+      case SMOLTTS_EPI_STORE: return launch_rows<SMOLTTS_EPI_STORE>(d, stream);
+      case SMOLTTS_EPI_RESID: return launch_rows<SMOLTTS_EPI_RESID>(d, stream);
+      case SMOLTTS_EPI_GELU: return launch_rows<SMOLTTS_EPI_GELU>(d, stream);
+      case SMOLTTS_EPI_SCALE_RESID: return launch_rows<SMOLTTS_EPI_SCALE_RESID>(d, stream);
+      case SMOLTTS_EPI_QKV_ROPE: return launch_rows<SMOLTTS_EPI_QKV_ROPE>(d, stream);
+      default: break;
+    }
   }
 #define ST_CASE(WF, PP, EE)                                                       \
   if ((a.w_is_fp32 != 0) == WF && P == PP && E == EE) return launch_mt<WF, PP, EE>(d, nwaves, stream);
