@@ -95,6 +95,8 @@ def main():
     rank, world, local = parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if os.environ.get("SMOLTTS_BENCH_ONE_DEVICE") == "1":  # rehearsal of the N > 1 path on a 1-GPU box (with SMOLTTS_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib = load_library()

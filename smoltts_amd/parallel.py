@@ -26,7 +26,7 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("SMOLTTS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -47,15 +47,23 @@ def broadcast_weights(arena: Optional[torch.Tensor], offsets, device, src: int =
     meta = [offsets, int(arena.numel())] if rank == src else [None, None]
     dist.broadcast_object_list(meta, src=src)
     offsets, nbytes = meta
+    if dist.get_backend() == "gloo":  # CPU transport (tests, single-GPU rehearsals): stage through host memory
+        buf = arena.cpu() if rank == src else torch.empty(nbytes, dtype=torch.uint8)
+        dist.broadcast(buf, src=src)
+        return buf.to(device), offsets
     buf = arena.to(device) if rank == src else torch.empty(nbytes, dtype=torch.uint8, device=device)
     dist.broadcast(buf, src=src)
     return buf, offsets
 
 
+def _reduce_device(device):
+    return "cpu" if dist.get_backend() == "gloo" else device
+
+
 def all_reduce_max(value: float, device) -> float:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_reduce_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -63,7 +71,7 @@ def all_reduce_max(value: float, device) -> float:
 def all_reduce_sum(value: float, device) -> float:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_reduce_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
