@@ -268,6 +268,153 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
   STAMP3(4);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Many-row variant (prompt prefill: M = all prompt tokens of all utterances): a workgroup owns 64
+// rows x 16*NTW*4 columns.  The X3 blocks of a 32-k chunk (4 row tiles x 3 pieces = 12 KiB, already in
+// B-fragment order) are copied into LDS once per chunk and shared by the 4 waves, each of which holds
+// NTW column tiles and accumulates the whole K itself: no split-K, no cross-wave reduction, the
+// activation operand leaves L2 once per 256 output columns instead of once per 16.
+template <int NTW, int EPI>
+__global__ __launch_bounds__(256) void gemm3_rows_kernel(Gemm3Dev p) {
+  __shared__ uint4 xs[12 * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int nchunks = p.K >> 5;
+  const int mtile0 = blockIdx.y * 4;
+  const int tile0 = (blockIdx.x * 4 + wave) * NTW;
+  constexpr bool kResid = EPI == SMOLTTS_EPI_RESID;
+
+  const char* sp[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int idx = tid + 256 * i, blk = idx >> 6, ln = idx & 63;
+    const int mt = blk / 3, pc = blk - mt * 3;
+    sp[i] = ((mtile0 + mt) * 16 < p.M) ? p.x3 + (size_t)(mtile0 + mt) * nchunks * 3072 + pc * 1024 + ln * 16 : nullptr;
+  }
+  const char* wb[NTW];
+  bool wv[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    wv[t] = (tile0 + t) * 16 < p.N;
+    wb[t] = p.w + (size_t)(tile0 + t) * nchunks * 1024 + lane * 16;
+  }
+  f32x4 acc[NTW][4];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  uint4 stage[3], wnext[NTW];
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) stage[i] = sp[i] ? *reinterpret_cast<const uint4*>(sp[i] + (size_t)c * 3072) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) wnext[t] = wv[t] ? *reinterpret_cast<const uint4*>(wb[t] + (size_t)c * 1024) : make_uint4(0, 0, 0, 0);
+  };
+  fetch(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();  // previous chunk fully consumed
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xs[tid + 256 * i] = stage[i];
+    bf16x8_t a[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) a[t] = __builtin_bit_cast(bf16x8_t, wnext[t]);
+    __syncthreads();
+    if (c + 1 < nchunks) fetch(c + 1);  // next chunk's loads fly under this chunk's MFMAs
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+        const bf16x8_t b = __builtin_bit_cast(bf16x8_t, xs[(mt * 3 + pc) * 64 + lane]);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b, acc[t][mt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue straight from the accumulators (inputs loaded here: amortised over the long K loop)
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = (mtile0 + mt) * 16 + r;
+    const bool mvalid = m < p.M;
+    const int mc = mvalid ? m : p.M - 1;
+    float rstd = 1.f;
+    if (p.ssq_in != nullptr) {
+      const int nt_in = p.K >> 4;
+      const float* ssp = p.ssq_in + (size_t)mc * nt_in;
+      float s = 0.f;
+      for (int i = q; i < nt_in; i += 4) s += ssp[i];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      rstd = 1.0f / sqrtf(s / (float)p.K + p.eps);
+    }
+    int pos = 0, slot = 0;
+    if (EPI == SMOLTTS_EPI_QKV_ROPE) { pos = p.row_pos[mc]; slot = p.row_slot[mc]; }
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int ntile = tile0 + t;
+      const int n0 = ntile * 16 + q * 4;
+      const bool valid = mvalid && n0 < p.N;
+      const int n0c = n0 < p.N ? n0 : p.N - 4;
+      float v[4] = {acc[t][mt][0] * rstd, acc[t][mt][1] * rstd, acc[t][mt][2] * rstd, acc[t][mt][3] * rstd};
+      if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n0c);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      if (EPI == SMOLTTS_EPI_STORE || EPI == SMOLTTS_EPI_RESID) {
+        if (kResid) {
+          const float4 rr = *reinterpret_cast<const float4*>(p.resid + (long)mc * p.ldo + n0c);
+          v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+        }
+        if (valid) {
+          *reinterpret_cast<float4*>(p.out + (long)m * p.ldo + n0) = make_float4(v[0], v[1], v[2], v[3]);
+          emit_x4(p.emit, m, n0, p.N >> 5, v[0], v[1], v[2], v[3]);
+        }
+        if (p.emit.ssq) {  // all 64 lanes take part in the shuffles
+          float s = valid ? ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) : 0.f;
+          s += __shfl_xor(s, 16);
+          s += __shfl_xor(s, 32);
+          if (q == 0 && mvalid && ntile * 16 < p.N) p.emit.ssq[(size_t)m * (p.N >> 4) + ntile] = s;
+        }
+      } else if (EPI == SMOLTTS_EPI_SWIGLU) {
+        if (valid) x3_emit2(p.x3_out, m, n0 >> 1, p.N >> 6, silu3(v[0]) * v[1], silu3(v[2]) * v[3]);
+      } else if (EPI == SMOLTTS_EPI_QKV_ROPE) {
+        if (valid) {
+          const int qd = p.n_q_heads * 64, kd = p.n_kv_heads * 64;
+          if (n0 < qd + kd && pos >= 0) {
+            const float4 cs = *reinterpret_cast<const float4*>(p.rope + ((long)pos * 32 + ((n0 & 63) >> 1)) * 2);
+            const float o0 = v[0] * cs.x - v[1] * cs.y, o1 = v[1] * cs.x + v[0] * cs.y;
+            const float o2 = v[2] * cs.z - v[3] * cs.w, o3 = v[3] * cs.z + v[2] * cs.w;
+            v[0] = o0; v[1] = o1; v[2] = o2; v[3] = o3;
+          }
+          const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+          if (n0 < qd) {
+            *reinterpret_cast<float4*>(p.out + (long)m * p.ldo + n0) = o;
+          } else if (pos >= 0 && pos < p.cache_len) {
+            const int nn = n0 - qd;
+            float* base = nn < kd ? p.kc : p.vc;
+            const int h = (nn < kd ? nn : nn - kd) >> 6, d = nn & 63;
+            *reinterpret_cast<float4*>(base + (((long)slot * p.n_kv_heads + h) * p.cache_len + pos) * 64 + d) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int EPI>
+static int launch3_rows(const Gemm3Dev& d, hipStream_t stream) {
+  const int ntiles = (d.N + 15) / 16;
+  const int NTW = ntiles >= 16 ? 4 : (ntiles >= 8 ? 2 : 1);
+  const dim3 grid((ntiles + 4 * NTW - 1) / (4 * NTW), (d.M + 63) / 64);
+  ST_REQUIRE(grid.y <= 65535, SMOLTTS_E_INVALID, "gemm3: M=%d too large for one launch", d.M);
+  if (NTW == 4) hipLaunchKernelGGL((gemm3_rows_kernel<4, EPI>), grid, dim3(256), 0, stream, d);
+  else if (NTW == 2) hipLaunchKernelGGL((gemm3_rows_kernel<2, EPI>), grid, dim3(256), 0, stream, d);
+  else hipLaunchKernelGGL((gemm3_rows_kernel<1, EPI>), grid, dim3(256), 0, stream, d);
+  ST_CHECK_HIP(hipGetLastError());
+  return SMOLTTS_OK;
+}
+
 template <int MT, int T, int U, int EPI>
 static int launch3_one(const Gemm3Dev& d, int nwaves, hipStream_t stream) {
   const int ntiles = (d.N + 15) / 16;
@@ -287,7 +434,8 @@ static int launch3_epi(const Gemm3Dev& d, hipStream_t stream) {
   int nwaves = (nchunks + 2) / 3;
   nwaves = nwaves < 1 ? 1 : (nwaves > 8 ? 8 : nwaves);  // <= 512 threads: 256 VGPRs per lane
   const int cpw = (nchunks + nwaves - 1) / nwaves;  // chunks per wave
-  if (d.M > 32)  // prefill: 64 rows per workgroup, weights re-used from registers
+  if (d.M >= 256) return launch3_rows<EPI>(d, stream);  // prefill: LDS-shared activation chunks, no split-K
+  if (d.M > 32)  // 33..255 rows: 64 rows per workgroup, weights re-used from registers
     return launch3_one<4, 1, 2, EPI>(d, nwaves < 4 ? 4 : nwaves, stream);
   // 16-row tiles go to separate workgroups (MT = 1); T = the smallest number of column tiles per
   // workgroup that keeps the grid within one workgroup per CU, so every CU takes the activation
