@@ -39,7 +39,8 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     srcs = [CSRC / s for s in SOURCES if (CSRC / s).exists()]
     objdir = CSRC / "build"
     objdir.mkdir(exist_ok=True)
-    flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+    flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result",
+             *os.environ.get("SMOLTTS_HIPCC_FLAGS", "").split()]  # extra -D switches for A/B experiments
 
     def compile_one(src: Path) -> Path:
         obj = objdir / (src.stem + ".o")

@@ -70,3 +70,33 @@ def load_mimi_state(path) -> Dict[str, torch.Tensor]:
     if p.is_dir():
         p = p / "model.safetensors"
     return load_file(str(p))
+
+
+def convert_training_checkpoint(pt_path, out_path="model.safetensors") -> Path:
+    """Trainer ``.pt`` -> ``model.safetensors`` in the MLX layout (train/convert_safetensors.py:7-17).
+
+    Same contract as the reference tool — reads ``["model_state_dict"]``, strips ``_orig_mod.``, flattens a
+    3-D depthwise head ``(n, d, cs)`` to ``(n*cs, d)`` — except that ``d`` is read from the tensor instead
+    of being fixed at 768, so 70m (d=576) and ``fast_dim != dim`` checkpoints convert too.  A bare state
+    dict (``model.pth``) is accepted as well.  dtypes are kept."""
+    from safetensors.torch import save_file
+
+    data = torch.load(pt_path, map_location="cpu", weights_only=True)
+    state = data["model_state_dict"] if isinstance(data, dict) and "model_state_dict" in data else data
+    state = {k.replace("_orig_mod.", ""): v for k, v in state.items()}
+    w = state.get("fast_output.weight")
+    if w is not None and w.dim() == 3:
+        state["fast_output.weight"] = w.permute(1, 0, 2).reshape(w.shape[1], -1).T
+    out = Path(out_path)
+    if out.is_dir():
+        out = out / "model.safetensors"
+    save_file({k: v.contiguous() for k, v in state.items()}, str(out))
+    return out
+
+
+if __name__ == "__main__":
+    import sys
+
+    if len(sys.argv) < 2:
+        raise SystemExit("usage: python -m smoltts_amd.checkpoint CHECKPOINT.pt [OUT.safetensors]")
+    print(convert_training_checkpoint(*sys.argv[1:3]))

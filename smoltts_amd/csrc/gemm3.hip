@@ -56,6 +56,18 @@ struct Gemm3Dev {
     }                                                                                         \
   } while (0)
 
+// Weight tiles are read once per launch by the one or two workgroups that own them: with
+// SMOLTTS_NT_W the loads carry the non-temporal hint (MI355X_MICROARCH.md 'nt-weights').
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_w16(const char* ptr) {
+#if defined(SMOLTTS_NT_W) && SMOLTTS_NT_W
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(ptr));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+#else
+  return *reinterpret_cast<const uint4*>(ptr);
+#endif
+}
+
 __device__ __forceinline__ float silu3(float x) { return x / (1.f + expf(-x)); }
 
 template <int MT, int T, int U, int EPI>
@@ -106,7 +118,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
       const bool cv = c < nchunks;
 #pragma unroll
       for (int t = 0; t < T; ++t)
-        wf[u][t] = (cv && wv[t]) ? *reinterpret_cast<const uint4*>(wb[t] + (size_t)c * 1024) : make_uint4(0, 0, 0, 0);
+        wf[u][t] = (cv && wv[t]) ? load_w16(wb[t] + (size_t)c * 1024) : make_uint4(0, 0, 0, 0);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll

@@ -15,6 +15,7 @@ BASELINE.json) and returned as fp32 tensors holding bf16-representable values.
 """
 from __future__ import annotations
 
+import dataclasses
 import math
 from typing import Dict
 
@@ -55,7 +56,7 @@ def synthetic_lm_state(cfg: RQTransformerModelArgs, seed: int = 0, bf16: bool = 
         st["output.weight"] = normal(cfg.vocab_size, cfg.dim)
     if cfg.fast_dim != cfg.dim:
         st["fast_project_in.weight"] = normal(cfg.fast_dim, cfg.dim)
-        st["fast_project_in.bias"] = torch.zeros(cfg.fast_dim)
+        st["fast_project_in.bias"] = normal(cfg.fast_dim)  # the reference zero-inits it; non-zero exercises the bias path
     n_fast_emb = cfg.codebook_size * (cfg.num_codebooks - 1) if cfg.depthwise_wte else cfg.codebook_size
     st["fast_embeddings.weight"] = normal(n_fast_emb, cfg.fast_dim)
     for i in range(cfg.n_fast_layer):
@@ -105,6 +106,11 @@ def named_config(name: str) -> RQTransformerModelArgs:
     the GPU box, which has no reference tree, can build them)."""
     if name == "tiny":
         return tiny_config()
+    if name == "tiny_nodup":  # code 0 carried by the slow token only: 7 depth steps, 8-row grid (modeling :344-360)
+        return dataclasses.replace(tiny_config(), duplicate_code_0=False)
+    if name == "tiny_proj":   # fast_dim != dim (fast_project_in Linear+bias :339-342), untied slow head, plain Linear depth head
+        return dataclasses.replace(tiny_config(), fast_dim=128, fast_n_head=2, fast_n_local_heads=1, fast_intermediate_size=256,
+                                   tie_word_embeddings=False, depthwise_output=False)
     s = _SIZES[name]
     return RQTransformerModelArgs(
         attention_qkv_bias=False, codebook_size=2048, dim=s["dim"], dropout=0.1,

@@ -43,6 +43,9 @@ CASES = [
     # name, config, seed, frames, [(text, voice)]
     ("tiny", "tiny", 7, 12, [("Hello world!", "heart"), ("The quick brown fox.", "sky")]),
     ("70m", "smoltts_byte_70m", 0, 16, [("Hello world!", "heart")]),
+    # checkpoint variants: duplicate_code_0=false; fast_dim != dim + untied head + Linear depth head
+    ("tiny_nodup", "tiny_nodup", 11, 12, [("Hello world!", "heart"), ("No duplicated code zero.", "emma")]),
+    ("tiny_proj", "tiny_proj", 12, 12, [("Hello world!", "heart"), ("A narrower depth transformer.", "liam")]),
     ("150m", "smoltts_byte_150m", 0, 16, [("Hello world!", "heart"), ("Streaming speech on MI355X, 12.5 frames per second.", "nova")]),
 ]
 
@@ -87,7 +90,10 @@ def main():
         indent=1, ensure_ascii=True))
     print("tokenizer pinned:", special)
 
+    only = set(sys.argv[1:])  # optional: names of the cases to (re)generate
     for name, cfgname, seed, frames, prompts in CASES:
+        if only and name not in only:
+            continue
         cfg = named_config(cfgname)
         state = synthetic_lm_state(cfg, seed=seed)
         fp = state_fingerprint(state)

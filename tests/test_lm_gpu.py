@@ -33,7 +33,7 @@ def _setup(cfgname, seed, numerics=None):
     return cfg, state, tok, eng, orc, state_fingerprint(state)
 
 
-@pytest.mark.parametrize("name", ["tiny", "70m", "150m"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_nodup", "tiny_proj", "70m", "150m"])
 def test_golden_grids(name, golden_dir):
     from smoltts_amd.engine import LMSession
 
@@ -76,7 +76,8 @@ def _check_vs_oracle(eng_grid, orc, prompt, label):
     return flips
 
 
-@pytest.mark.parametrize("cfgname,B,frames,mode", [("tiny", 5, 24, "torch"), ("tiny", 3, 16, "mlx"), ("smoltts_byte_70m", 3, 12, "torch"),
+@pytest.mark.parametrize("cfgname,B,frames,mode", [("tiny", 5, 24, "torch"), ("tiny", 3, 16, "mlx"), ("tiny_nodup", 4, 16, "torch"), ("tiny_nodup", 3, 8, "mlx"),
+                                                   ("tiny_proj", 4, 16, "torch"), ("smoltts_byte_70m", 3, 12, "torch"),
                                                    ("smoltts_byte_150m", 33, 6, "torch")])
 def test_batched_ragged_vs_oracle(cfgname, B, frames, mode):
     from smoltts_amd.config import NumericsMode

@@ -14,7 +14,7 @@ def _lm(cfgname, seed):
     return cfg, state, LMOracle(OracleLMConfig.from_dict(cfg.__dict__), state), state_fingerprint(state)
 
 
-@pytest.mark.parametrize("name", ["tiny", "70m"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_nodup", "tiny_proj", "70m"])
 def test_lm_oracle_reproduces_goldens(name, golden_dir):
     g = np.load(golden_dir / f"lm_{name}.npz")
     cfg, state, orc, fp = _lm(str(g["config_name"]), int(g["seed"]))
