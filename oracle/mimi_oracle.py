@@ -160,3 +160,101 @@ class MimiDecodeOracle:
         e2 = self.transformer(e1.transpose(1, 2))
         pcm = self.seanet(e2.transpose(1, 2))
         return {"rvq": e0.transpose(1, 2), "upsample": e1.transpose(1, 2), "transformer": e2, "pcm": pcm}
+
+
+# =============================================================================================
+# Encode half (voice-clone prompts): MimiModel.encode, mlx_inference/src/smoltts_mlx/codec/mimi.py:64-71
+# =============================================================================================
+def _extra_padding(length: int, k_eff: int, stride: int) -> int:
+    """MimiConv1d._get_extra_padding_for_conv1d (conv.py:112-118)."""
+    padding_total = k_eff - stride
+    n_frames = math.ceil((length - k_eff + padding_total) / stride + 1) - 1
+    return n_frames * stride + k_eff - padding_total - length
+
+
+def _pad_conv1d(x: Tensor, w: Tensor, b: Optional[Tensor], stride: int = 1, mode: str = "constant", extra_right: bool = False) -> Tensor:
+    """MimiConv1d.__call__ (conv.py:120-128) through causal_pad1d (conv.py:25-41), which puts ALL padding —
+    k_eff - stride plus the stride-alignment extra — on the left (``pad_tuple[-2] = (left + right, 0)``).
+    ``extra_right`` puts the extra on the right instead, as ``transformers.MimiConv1d`` does; the two agree
+    whenever every strided conv sees a length that is a multiple of its stride (audio length % 1920 == 0)."""
+    k = w.shape[-1]
+    extra = _extra_padding(x.shape[-1], k, stride)
+    left, right = (k - stride, extra) if extra_right else (k - stride + extra, 0)
+    if mode == "constant":
+        x = F.pad(x, (left, right))
+    else:  # "edge" (mimi.py:45): repeat the first / last sample
+        x = F.pad(x, (left, right), mode="replicate")
+    return F.conv1d(x, w, b, stride=stride)
+
+
+class MimiEncodeOracle:
+    """pcm (B, 1, L) -> codes (B, nq, ceil(L / 1920)).  TEST INFRASTRUCTURE ONLY (see the module header).
+
+    * SEANet encoder   codec/seanet.py:52-96 (conv k7; per ratio 4,5,6,8: resnet block, ELU, strided conv
+                       k = 2*ratio; ELU; conv k3), padding as ``_pad_conv1d``
+    * transformer      codec/transformer.py (same block as the decoder's; causal; ``window`` as above)
+    * downsample       codec/mimi.py:37-46 (Conv1d 512->512, k4, stride 2, no bias, "edge" padding)
+    * RVQ encode       codec/rvq.py:16-22 (cdist), :54-64 (argmin), :99-116 (residual loop after the
+                       group's 1x1 ``input_proj``), :157-177 (semantic group on the embeddings, acoustic
+                       group on the same embeddings, not on the semantic residual)
+    Pinned by tests/golden/mimi_enc_hf.npz (``transformers.MimiModel.encode`` on seeded weights).
+    """
+
+    def __init__(self, state: Dict[str, Tensor], num_codebooks: int = 8, window: int = 0, extra_right: bool = False):
+        self.st = {k: v.float() for k, v in state.items()}
+        self.nq = num_codebooks
+        self.extra_right = extra_right
+        # the encoder transformer is the decoder's block with other weights: reuse that restatement
+        self._tr = MimiDecodeOracle({k.replace("encoder_transformer.", "decoder_transformer."): v for k, v in self.st.items()
+                                     if k.startswith("encoder_transformer.")}, num_codebooks, window)
+
+    def seanet(self, x: Tensor) -> Tensor:
+        """x (B, 1, L) -> (B, 512, ceil(L/960))."""
+        g = lambda k: self.st["encoder.layers." + k]
+        pc = lambda x, key, stride=1: _pad_conv1d(x, g(key + ".conv.weight"), g(key + ".conv.bias"), stride, extra_right=self.extra_right)
+        x = pc(x, "0")
+        li = 1
+        for r in reversed(RATIOS):
+            y = pc(F.elu(x), f"{li}.block.1")
+            y = pc(F.elu(y), f"{li}.block.3")
+            x = x + y
+            x = pc(F.elu(x), str(li + 2), r)
+            li += 3
+        return pc(F.elu(x), "14")
+
+    def downsample(self, x: Tensor) -> Tensor:
+        return _pad_conv1d(x, self.st["downsample.conv.weight"], None, 2, mode="edge", extra_right=self.extra_right)
+
+    def embeddings(self, pcm: Tensor) -> Tensor:
+        """Pre-quantisation latents (B, 512, F)."""
+        e = self.seanet(pcm.float())
+        e = self._tr.transformer(e.transpose(1, 2)).transpose(1, 2)
+        return self.downsample(e)
+
+    def _codebook(self, prefix: str) -> Tensor:
+        es, cu = self.st[prefix + "embed_sum"], self.st[prefix + "cluster_usage"]
+        return es / torch.clamp(cu, min=1e-5)[:, None]
+
+    def rvq_encode(self, emb: Tensor, return_margin: bool = False):
+        """emb (B, 512, F) -> codes (B, nq, F) [, smallest best-vs-second distance gap seen]."""
+        B, _, Fr = emb.shape
+        out, min_gap = [], float("inf")
+        for grp, n in (("semantic", 1), ("acoustic", self.nq - 1)):
+            p = f"quantizer.{grp}_residual_vector_quantizer."
+            r = F.conv1d(emb, self.st[p + "input_proj.weight"]).transpose(1, 2).reshape(B * Fr, -1)  # rows (b, f)
+            for i in range(n):
+                cb = self._codebook(p + f"layers.{i}.codebook.")
+                d2 = (r * r).sum(-1, keepdim=True) + (cb * cb).sum(-1)[None, :] - 2.0 * (r @ cb.T)
+                d = d2.sqrt()  # rvq.py:22
+                idx = d.argmin(-1)
+                if return_margin:
+                    top2 = torch.topk(d2, 2, dim=-1, largest=False).values
+                    min_gap = min(min_gap, float((top2[:, 1] - top2[:, 0]).min()))
+                r = r - cb[idx]
+                out.append(idx.view(B, Fr))
+        codes = torch.stack(out, dim=1)
+        return (codes, min_gap) if return_margin else codes
+
+    @torch.no_grad()
+    def encode(self, pcm: Tensor) -> Tensor:
+        return self.rvq_encode(self.embeddings(pcm))

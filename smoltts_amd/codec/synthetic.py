@@ -70,3 +70,62 @@ def synthetic_mimi_state(seed: int = 0, num_codebooks: int = 8, n_layers: int = 
     # lift the output level to speech-like amplitude so that absolute PCM tolerances are meaningful
     st["decoder.layers.14.conv.weight"] = st["decoder.layers.14.conv.weight"] * 6.0
     return st
+
+
+def synthetic_mimi_encoder_state(seed: int = 0, n_layers: int = 8) -> Dict[str, torch.Tensor]:
+    """Encoder-side keys (SEANet encoder, encoder transformer, downsample, the RVQ ``input_proj``s) for the
+    voice-clone path; merge with ``synthetic_mimi_state`` (which holds the codebooks).  Own RNG stream, so
+    the decoder-side fixtures do not move."""
+    rng = np.random.Generator(np.random.PCG64(seed + 7919))
+
+    def uni(shape, fan_in):
+        b = 1.0 / math.sqrt(fan_in)
+        return torch.from_numpy(rng.uniform(-b, b, size=shape).astype(np.float32))
+
+    def nrm(shape, std=1.0, mean=0.0):
+        return torch.from_numpy((rng.standard_normal(shape, dtype=np.float32) * np.float32(std) + np.float32(mean)))
+
+    st: Dict[str, torch.Tensor] = {}
+
+    def conv(key, cout, cin, k, gain=1.0):
+        st[f"encoder.layers.{key}.conv.weight"] = uni((cout, cin, k), cin * k) * gain
+        st[f"encoder.layers.{key}.conv.bias"] = uni((cout,), cin * k)
+
+    conv("0", 64, 1, 7)
+    ch, li = 64, 1
+    for r in reversed(RATIOS):
+        conv(f"{li}.block.1", ch // 2, ch, 3)
+        conv(f"{li}.block.3", ch, ch // 2, 1)
+        conv(str(li + 2), 2 * ch, ch, 2 * r, gain=2.0)  # keep the signal from fading through the ELUs
+        ch *= 2
+        li += 3
+    conv("14", 512, 1024, 3, gain=2.0)
+    for l in range(n_layers):
+        p = f"encoder_transformer.layers.{l}."
+        for nm in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            st[p + f"self_attn.{nm}.weight"] = uni((512, 512), 512)
+        st[p + "mlp.fc1.weight"] = uni((2048, 512), 512)
+        st[p + "mlp.fc2.weight"] = uni((512, 2048), 2048)
+        for nm in ("input_layernorm", "post_attention_layernorm"):
+            st[p + nm + ".weight"] = nrm((512,), 0.05, 1.0)
+            st[p + nm + ".bias"] = nrm((512,), 0.05)
+        st[p + "self_attn_layer_scale.scale"] = nrm((512,), 0.02, 0.2)
+        st[p + "mlp_layer_scale.scale"] = nrm((512,), 0.02, 0.2)
+    st["downsample.conv.weight"] = uni((512, 512, 4), 512 * 4) * 2.0
+    for grp in ("semantic", "acoustic"):
+        # latents of O(1) against N(0,1) codebooks: scale the projection so residuals are codebook-sized
+        st[f"quantizer.{grp}_residual_vector_quantizer.input_proj.weight"] = uni((256, 512, 1), 512) * 24.0
+    return st
+
+
+def synthetic_pcm(n_samples: int, seed: int = 0) -> np.ndarray:
+    """Speech-like test signal in [-1, 1]: a few drifting harmonics under a slow envelope, plus noise."""
+    rng = np.random.Generator(np.random.PCG64(seed + 104729))
+    t = np.arange(n_samples, dtype=np.float64) / 24000.0
+    x = np.zeros(n_samples)
+    for _ in range(5):
+        f0, a, ph = rng.uniform(90, 1800), rng.uniform(0.05, 0.25), rng.uniform(0, 2 * np.pi)
+        x += a * np.sin(2 * np.pi * f0 * t * (1 + 0.05 * np.sin(2 * np.pi * rng.uniform(0.5, 3) * t)) + ph)
+    x *= 0.6 + 0.4 * np.sin(2 * np.pi * 2.5 * t + rng.uniform(0, 6))
+    x += 0.02 * rng.standard_normal(n_samples)
+    return np.clip(x, -1, 1).astype(np.float32)

@@ -17,7 +17,7 @@ import torch
 
 ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
-from smoltts_amd.codec.synthetic import synthetic_mimi_state  # noqa: E402
+from smoltts_amd.codec.synthetic import synthetic_mimi_encoder_state, synthetic_mimi_state, synthetic_pcm  # noqa: E402
 
 
 def main():
@@ -36,6 +36,24 @@ def main():
     np.savez_compressed(Path(__file__).resolve().parent / "mimi_hf.npz", seed=seed, codes=codes.numpy().astype(np.int32),
                         pcm=pcm.numpy().astype(np.float32), fingerprint=fp)
     print("wrote mimi_hf.npz", pcm.shape, float(pcm.pow(2).mean().sqrt()))
+
+    # ---- encode half (voice-clone prompts): MimiModel.encode on seeded encoder-side weights.
+    # 7680 samples = 4 whole frames (both padding conventions agree); 6460 is ragged: transformers pads the
+    # stride-alignment extra on the right, the reference's MLX conv on the left (oracle ``extra_right``).
+    st = {**synthetic_mimi_state(seed=seed), **synthetic_mimi_encoder_state(seed=seed)}
+    m = MimiModel(MimiConfig()).eval()
+    res = m.load_state_dict(st, strict=False)
+    assert not res.unexpected_keys
+    save = {"seed": seed, "pcm_seed": 1, "lengths": np.array([7680, 6460])}
+    for L in (7680, 6460):
+        x = torch.from_numpy(synthetic_pcm(L, 1))[None, None]
+        with torch.no_grad():
+            save[f"codes_{L}"] = m.encode(x, num_quantizers=8).audio_codes.numpy().astype(np.int32)
+            e = m.encoder(x)
+            e = m.encoder_transformer(e.transpose(1, 2))[0].transpose(1, 2)
+            save[f"emb_{L}"] = m.downsample(e).numpy().astype(np.float32)
+    np.savez_compressed(Path(__file__).resolve().parent / "mimi_enc_hf.npz", **save)
+    print("wrote mimi_enc_hf.npz", {k: getattr(v, "shape", v) for k, v in save.items()})
 
 
 if __name__ == "__main__":
