@@ -215,6 +215,49 @@ int smoltts_mimi_decode_chunk(SmolttsMimiSession* s, const int32_t* codes_dev, i
                               int32_t frame_stride, int32_t code_offset, int32_t batch,
                               int32_t n_frames, float* pcm_dev, int64_t pcm_stride, void* stream);
 
+/* ------------------------------------------------------------------------------ Mimi encoder
+ * Voice-clone prompts: MimiModel.encode (mlx_inference/src/smoltts_mlx/codec/mimi.py:64-71) =
+ * SEANet encoder (codec/seanet.py:52-96) -> encoder transformer (codec/transformer.py:134-150) ->
+ * downsample conv (mimi.py:37-46) -> split RVQ encode (codec/rvq.py:99-116,157-177).  One utterance
+ * per call, whole signal at once, as in the reference (no streaming encode there either). */
+typedef struct SmolttsMimiEncConfig {
+  int32_t num_codebooks;     /* codebooks produced per frame: 1 semantic + (num_codebooks-1) acoustic */
+  int32_t n_layers;          /* encoder transformer layers (8) */
+  int32_t window;            /* attention window in positions (25 Hz); 0 = unbounded (reference MLX) */
+  int32_t max_positions;     /* rows of the RoPE table = longest signal in 960-sample steps */
+  int32_t extra_right;       /* 0: the stride-alignment padding goes on the left with the causal padding
+                                (reference, codec/conv.py:25-41); 1: on the right (transformers.MimiConv1d) */
+} SmolttsMimiEncConfig;
+
+typedef struct SmolttsMimiEncWeights {
+  uint64_t conv0_w;          /* fp32 [64][8]: the 7 taps of encoder.layers.0 (1 -> 64 channels), 8th = 0 */
+  uint64_t conv0_b;          /* fp32 [64] */
+  SmolttsMimiConv convs[13]; /* per ratio 4,5,6,8: res.conv3, res.conv1, strided conv (k = 2*ratio); then the
+                                final conv k3 (1024 -> 512); GEMM form [cout][k*cin] */
+  SmolttsMimiLayerWeights layers[SMOLTTS_MIMI_MAX_LAYERS];
+  uint64_t rope;             /* fp32 [max_positions][32][2] */
+  uint64_t downsample_w;     /* fp32 T16x32 [512][4*512], no bias */
+  uint64_t in_proj[2];       /* fp32 T16x32 [256][512]: semantic, acoustic group input_proj */
+  uint64_t codebooks_t;      /* fp32 T16x32 [num_codebooks][2048][256]: embed_sum / max(usage, 1e-5) */
+  uint64_t codebooks;        /* the same rows, row-major (residual update) */
+  uint64_t codebook_sq;      /* fp32 [num_codebooks][2048] squared norms of the rows */
+} SmolttsMimiEncWeights;
+
+typedef struct SmolttsMimiEncoder SmolttsMimiEncoder;
+
+int smoltts_mimi_encoder_create(const SmolttsMimiEncConfig* cfg, const SmolttsMimiEncWeights* offsets,
+                                const void* arena_dev, size_t arena_bytes, SmolttsMimiEncoder** out);
+void smoltts_mimi_encoder_destroy(SmolttsMimiEncoder* e);
+/* Frames produced for n_samples of 24 kHz audio: ceil(ceil(n/960)/2). */
+int32_t smoltts_mimi_encode_frames(int32_t n_samples);
+size_t smoltts_mimi_encode_workspace_bytes(const SmolttsMimiEncoder* e, int32_t n_samples);
+/* pcm_dev float [n_samples] -> codes_dev int32 [num_codebooks][frames] (row q = codebook q).
+ * Optional outputs (NULL to skip): emb_dev float [frames][512] pre-quantisation latents; gap_dev float
+ * [num_codebooks][frames] squared-distance gap between the chosen and the second-nearest entry. */
+int smoltts_mimi_encode(SmolttsMimiEncoder* e, const float* pcm_dev, int32_t n_samples, int32_t* codes_dev,
+                        float* emb_dev, float* gap_dev, void* workspace_dev, size_t workspace_bytes,
+                        void* stream);
+
 /* --------------------------------------------------------------- operator-level test entry points */
 enum {  /* prologue applied to the activation operand */
   SMOLTTS_PRO_NONE = 0,

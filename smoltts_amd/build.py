@@ -15,7 +15,7 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libsmoltts_hip.so"
-SOURCES = ["api.hip", "gemm.hip", "gemm3.hip", "attention.hip", "small_ops.hip", "lm_engine.hip", "mimi_engine.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm3.hip", "attention.hip", "small_ops.hip", "lm_engine.hip", "mimi_engine.hip", "mimi_encoder.hip"]
 ARCH = "gfx950"
 
 
@@ -35,7 +35,7 @@ def _stale(target: Path, deps) -> bool:
 
 def build_library(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
-    headers = [CSRC / "common.h", CSRC / "x3.h", CSRC.parents[1] / "include" / "smoltts_hip.h"]
+    headers = [CSRC / "common.h", CSRC / "x3.h", CSRC / "mimi_common.h", CSRC.parents[1] / "include" / "smoltts_hip.h"]
     srcs = [CSRC / s for s in SOURCES if (CSRC / s).exists()]
     objdir = CSRC / "build"
     objdir.mkdir(exist_ok=True)

@@ -1,0 +1,33 @@
+// Pieces shared by the Mimi decoder engine (mimi_engine.hip) and encoder (mimi_encoder.hip).
+#pragma once
+#include "common.h"
+
+namespace smoltts {
+
+constexpr int MIMI_D = 512, MIMI_HEADS = 8, MIMI_FF = 2048;
+
+struct MimiTransformerBufs {
+  float *tx, *tn, *tq, *ta, *th;  // rows x [512 | 512 | 512 | 512 | 2048]
+  float *kc, *vc;                 // [n_layers][slots][8][cache_len][64]
+  size_t layer_stride;            // floats between two layers' caches
+  const int *row_pos, *row_slot;  // [rows]
+};
+
+// The 8-layer pre-LayerNorm block stack of codec/transformer.py:109-150 over `rows` rows (`rows_per_slot`
+// consecutive rows per slot).  The last layer's MLP output (+ residual) goes to `last_out` (row stride 512,
+// slot stride `last_bstride` floats) instead of tx.  Implemented in mimi_engine.hip.
+int run_mimi_transformer(const char* arena, const SmolttsMimiLayerWeights* layers, int n_layers, const float* rope,
+                         int cache_len, int window, const MimiTransformerBufs& b, int rows, int rows_per_slot,
+                         float* last_out, int64_t last_bstride, hipStream_t st);
+
+// row_slot[m] = m / rows_per_slot, row_pos[m] = pos0 + m % rows_per_slot
+int launch_mimi_rows(int n_rows, int rows_per_slot, int pos0, int* row_pos, int* row_slot, hipStream_t st);
+
+inline SmolttsGemmArgs mimi_gemm_f32(const void* w, const float* x, long ldx, int M, int N, int K) {
+  SmolttsGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.w_dev = w; a.w_is_fp32 = 1; a.x_dev = x; a.ldx = ldx; a.M = M; a.N = N; a.K = K;
+  return a;
+}
+
+}  // namespace smoltts

@@ -16,12 +16,12 @@
 
 #include <new>
 
-#include "common.h"
+#include "mimi_common.h"
 
 using namespace smoltts;
 
 namespace {
-constexpr int D = 512, HEADS = 8, FF = 2048, NCONV = 14, NBUF = 14;
+constexpr int D = MIMI_D, HEADS = MIMI_HEADS, FF = MIMI_FF, NCONV = 14, NBUF = 14;
 constexpr int SAMPLES = 1920;
 // buffer i feeds conv i (i < 13); channels, halo rows and rows per frame of each conv input
 // conv order: conv0 | convT1 res1.c3 res1.c1 | convT2 ... | convT4 res4.c3 res4.c1 | final
@@ -160,14 +160,62 @@ __global__ __launch_bounds__(256) void halo_shift_kernel(HaloDesc d) {
   for (int j = threadIdx.x; j < n; j += 256) base[j] = sh[j];
 }
 
-SmolttsGemmArgs gemm_f32(const void* w, const float* x, long ldx, int M, int N, int K) {
-  SmolttsGemmArgs a;
-  memset(&a, 0, sizeof(a));
-  a.w_dev = w; a.w_is_fp32 = 1; a.x_dev = x; a.ldx = ldx; a.M = M; a.N = N; a.K = K;
-  return a;
+}  // namespace
+
+namespace smoltts {
+
+int launch_mimi_rows(int n_rows, int rows_per_slot, int pos0, int* row_pos, int* row_slot, hipStream_t st) {
+  hipLaunchKernelGGL(mimi_rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, st, n_rows, rows_per_slot, pos0, row_pos, row_slot);
+  ST_CHECK_HIP(hipGetLastError());
+  return SMOLTTS_OK;
 }
 
-}  // namespace
+int run_mimi_transformer(const char* A, const SmolttsMimiLayerWeights* layers, int n_layers, const float* rope, int cache_len,
+                         int window, const MimiTransformerBufs& b, int R, int Tt, float* last_out, int64_t last_bstride,
+                         hipStream_t st) {
+  for (int l = 0; l < n_layers; ++l) {
+    const SmolttsMimiLayerWeights& lw = layers[l];
+    float* kc = b.kc + l * b.layer_stride;
+    float* vc = b.vc + l * b.layer_stride;
+    ST_TRY(launch_layernorm(b.tx, (const float*)(A + lw.ln1_w), (const float*)(A + lw.ln1_b), R, D, 1e-5f, b.tn, st));
+    {
+      SmolttsGemmArgs a = mimi_gemm_f32(A + lw.wqkv, b.tn, D, R, 3 * D, D);
+      a.epilogue = SMOLTTS_EPI_QKV_ROPE; a.out_dev = b.tq; a.ldo = D;
+      a.rope_dev = rope; a.row_pos_dev = b.row_pos; a.row_slot_dev = b.row_slot;
+      a.k_cache_dev = kc; a.v_cache_dev = vc;
+      a.n_q_heads = HEADS; a.n_kv_heads = HEADS; a.cache_len = cache_len;
+      ST_TRY(launch_gemm(a, st));
+    }
+    ST_TRY(launch_attention(b.tq, kc, vc, b.row_pos, b.row_slot, R, HEADS, HEADS, cache_len, window, b.ta, nullptr, st));
+    {
+      SmolttsGemmArgs a = mimi_gemm_f32(A + lw.wo, b.ta, D, R, D, D);
+      a.epilogue = SMOLTTS_EPI_SCALE_RESID; a.scale_dev = (const float*)(A + lw.ls1);
+      a.resid_dev = b.tx; a.out_dev = b.tx; a.ldo = D;
+      ST_TRY(launch_gemm(a, st));
+    }
+    ST_TRY(launch_layernorm(b.tx, (const float*)(A + lw.ln2_w), (const float*)(A + lw.ln2_b), R, D, 1e-5f, b.tn, st));
+    {
+      SmolttsGemmArgs a = mimi_gemm_f32(A + lw.fc1, b.tn, D, R, FF, D);
+      a.epilogue = SMOLTTS_EPI_GELU; a.out_dev = b.th; a.ldo = FF;
+      ST_TRY(launch_gemm(a, st));
+    }
+    {
+      SmolttsGemmArgs a = mimi_gemm_f32(A + lw.fc2, b.th, FF, R, D, FF);
+      a.epilogue = SMOLTTS_EPI_SCALE_RESID; a.scale_dev = (const float*)(A + lw.ls2);
+      a.resid_dev = b.tx; a.ldr = D; a.r_bstride = (int64_t)Tt * D; a.rows_per_batch = Tt;
+      a.x_bstride = (int64_t)Tt * FF;
+      if (l + 1 < n_layers) {
+        a.out_dev = b.tx; a.ldo = D; a.o_bstride = (int64_t)Tt * D;
+      } else {
+        a.out_dev = last_out; a.ldo = D; a.o_bstride = last_bstride;
+      }
+      ST_TRY(launch_gemm(a, st));
+    }
+  }
+  return SMOLTTS_OK;
+}
+
+}  // namespace smoltts
 
 extern "C" {
 
@@ -260,48 +308,15 @@ int smoltts_mimi_decode_chunk(SmolttsMimiSession* s, const int32_t* codes_dev, i
                      c.num_codebooks, F, (const float*)(A + m->w.rvq_table), (const float*)(A + m->w.upsample_w),
                      s->carry[s->parity], s->carry[s->parity ^ 1], s->tx);
   ST_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(mimi_rows_kernel, dim3((R + 255) / 256), dim3(256), 0, st, R, Tt, s->positions, s->row_pos, s->row_slot);
-  ST_CHECK_HIP(hipGetLastError());
+  ST_TRY(launch_mimi_rows(R, Tt, s->positions, s->row_pos, s->row_slot, st));
 
-  // 2. decoder transformer (transformer.py:109-131)
-  const size_t l_stride = (size_t)s->B * HEADS * c.max_positions * 64;
-  for (int l = 0; l < c.n_layers; ++l) {
-    const SmolttsMimiLayerWeights& lw = m->w.layers[l];
-    ST_TRY(launch_layernorm(s->tx, (const float*)(A + lw.ln1_w), (const float*)(A + lw.ln1_b), R, D, 1e-5f, s->tn, st));
-    {
-      SmolttsGemmArgs a = gemm_f32(A + lw.wqkv, s->tn, D, R, 3 * D, D);
-      a.epilogue = SMOLTTS_EPI_QKV_ROPE; a.out_dev = s->tq; a.ldo = D;
-      a.rope_dev = (const float*)(A + m->w.rope); a.row_pos_dev = s->row_pos; a.row_slot_dev = s->row_slot;
-      a.k_cache_dev = s->kc + l * l_stride; a.v_cache_dev = s->vc + l * l_stride;
-      a.n_q_heads = HEADS; a.n_kv_heads = HEADS; a.cache_len = c.max_positions;
-      ST_TRY(launch_gemm(a, st));
-    }
-    ST_TRY(launch_attention(s->tq, s->kc + l * l_stride, s->vc + l * l_stride, s->row_pos, s->row_slot, R, HEADS, HEADS,
-                            c.max_positions, c.window, s->ta, nullptr, st));
-    {
-      SmolttsGemmArgs a = gemm_f32(A + lw.wo, s->ta, D, R, D, D);
-      a.epilogue = SMOLTTS_EPI_SCALE_RESID; a.scale_dev = (const float*)(A + lw.ls1);
-      a.resid_dev = s->tx; a.out_dev = s->tx; a.ldo = D;
-      ST_TRY(launch_gemm(a, st));
-    }
-    ST_TRY(launch_layernorm(s->tx, (const float*)(A + lw.ln2_w), (const float*)(A + lw.ln2_b), R, D, 1e-5f, s->tn, st));
-    {
-      SmolttsGemmArgs a = gemm_f32(A + lw.fc1, s->tn, D, R, FF, D);
-      a.epilogue = SMOLTTS_EPI_GELU; a.out_dev = s->th; a.ldo = FF;
-      ST_TRY(launch_gemm(a, st));
-    }
-    {
-      SmolttsGemmArgs a = gemm_f32(A + lw.fc2, s->th, FF, R, D, FF);
-      a.epilogue = SMOLTTS_EPI_SCALE_RESID; a.scale_dev = (const float*)(A + lw.ls2);
-      a.resid_dev = s->tx; a.ldr = D; a.r_bstride = (int64_t)Tt * D; a.rows_per_batch = Tt;
-      a.x_bstride = (int64_t)Tt * FF;
-      if (l + 1 < c.n_layers) {
-        a.out_dev = s->tx; a.ldo = D; a.o_bstride = (int64_t)Tt * D;
-      } else {  // last layer: write straight into conv0's input buffer, behind its halo
-        a.out_dev = s->buf[0] + (size_t)BUF_HALO[0] * BUF_C[0]; a.ldo = D; a.o_bstride = (int64_t)s->buf_bstride[0];
-      }
-      ST_TRY(launch_gemm(a, st));
-    }
+  // 2. decoder transformer (transformer.py:109-131); the last layer writes straight into conv0's input
+  //    buffer, behind its halo
+  {
+    MimiTransformerBufs tb{s->tx, s->tn, s->tq, s->ta, s->th, s->kc, s->vc, (size_t)s->B * HEADS * c.max_positions * 64,
+                           s->row_pos, s->row_slot};
+    ST_TRY(run_mimi_transformer(A, m->w.layers, c.n_layers, (const float*)(A + m->w.rope), c.max_positions, c.window, tb, R, Tt,
+                                s->buf[0] + (size_t)BUF_HALO[0] * BUF_C[0], (int64_t)s->buf_bstride[0], st));
   }
 
   // 3. SEANet decoder (seanet.py:105-139) as 14 GEMMs over halo-prefixed channel-last buffers.
@@ -313,7 +328,7 @@ int smoltts_mimi_decode_chunk(SmolttsMimiSession* s, const int32_t* codes_dev, i
     const int Tin = BUF_RPF[i] * F;
     const int K = cv.transposed ? 2 * cv.cin : cv.k * cv.cin;
     const int N = cv.transposed ? cv.stride * cv.cout : cv.cout;
-    SmolttsGemmArgs a = gemm_f32(A + cv.w, s->buf[i], cv.cin, batch * Tin, N, K);
+    SmolttsGemmArgs a = mimi_gemm_f32(A + cv.w, s->buf[i], cv.cin, batch * Tin, N, K);
     a.rows_per_batch = Tin; a.x_bstride = (int64_t)s->buf_bstride[i];
     a.bias_dev = (const float*)(A + cv.b);
     a.prologue = SMOLTTS_PRO_NONE;

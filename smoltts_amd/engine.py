@@ -75,6 +75,16 @@ class MimiWeights(C.Structure):
                 ("layers", MimiLayerWeights * MIMI_MAX_LAYERS), ("convs", MimiConv * 14)]
 
 
+class MimiEncConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("num_codebooks", "n_layers", "window", "max_positions", "extra_right")]
+
+
+class MimiEncWeights(C.Structure):
+    _fields_ = [("conv0_w", C.c_uint64), ("conv0_b", C.c_uint64), ("convs", MimiConv * 13),
+                ("layers", MimiLayerWeights * MIMI_MAX_LAYERS), ("rope", C.c_uint64), ("downsample_w", C.c_uint64),
+                ("in_proj", C.c_uint64 * 2), ("codebooks_t", C.c_uint64), ("codebooks", C.c_uint64), ("codebook_sq", C.c_uint64)]
+
+
 PRO_NONE, PRO_RMSNORM, PRO_ELU = 0, 1, 2
 EPI_STORE, EPI_RESID, EPI_SWIGLU, EPI_GELU, EPI_SCALE_RESID, EPI_QKV_ROPE = range(6)
 
@@ -88,6 +98,8 @@ _EXPORTS = [
     "smoltts_mimi_decode_chunk", "smoltts_k_gemm", "smoltts_k_attention", "smoltts_k_embed", "smoltts_k_argmax",
     "smoltts_k_layernorm", "smoltts_profile_begin", "smoltts_profile_end", "smoltts_k_gemm3", "smoltts_k_x3_pack",
     "smoltts_debug_duplicate", "smoltts_session_drop_graph", "smoltts_session_set_sampling", "smoltts_k_sample",
+    "smoltts_mimi_encoder_create", "smoltts_mimi_encoder_destroy", "smoltts_mimi_encode_frames",
+    "smoltts_mimi_encode_workspace_bytes", "smoltts_mimi_encode",
 ]
 
 
@@ -138,6 +150,15 @@ def load_library(path: Optional[Path] = None):
                                      C.c_int32, C.c_void_p, C.c_void_p]
     lib.smoltts_debug_duplicate.argtypes = [C.c_int32, C.c_int32]
     lib.smoltts_session_drop_graph.argtypes = [C.c_void_p]
+    lib.smoltts_mimi_encoder_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.smoltts_mimi_encoder_destroy.argtypes = [C.c_void_p]
+    lib.smoltts_mimi_encoder_destroy.restype = None
+    lib.smoltts_mimi_encode_frames.argtypes = [C.c_int32]
+    lib.smoltts_mimi_encode_frames.restype = C.c_int32
+    lib.smoltts_mimi_encode_workspace_bytes.argtypes = [C.c_void_p, C.c_int32]
+    lib.smoltts_mimi_encode_workspace_bytes.restype = C.c_size_t
+    lib.smoltts_mimi_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                        C.c_void_p]
     lib.smoltts_profile_begin.argtypes = [C.c_int32] * 4
     lib.smoltts_profile_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     if lib.smoltts_abi_version() != 1:
@@ -369,6 +390,73 @@ class MimiEngine:
     def close(self):
         if getattr(self, "handle", None):
             self.lib.smoltts_mimi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MimiEncoder:
+    """PCM -> RVQ codes (``MimiModel.encode``, codec/mimi.py:64-71) for voice-clone prompts.
+
+    ``extra_right=False`` pads like the reference's MLX convs (everything on the left), ``True`` like
+    ``transformers.MimiConv1d``; they agree for signals of whole frames (multiples of 1920 samples)."""
+
+    def __init__(self, state: Optional[Dict[str, torch.Tensor]], num_codebooks: int = 8, window: int = 0, max_positions: int = 2048,
+                 extra_right: bool = False, arena: Optional[torch.Tensor] = None, offsets=None):
+        self.lib = load_library()
+        self.device = _require_gpu()
+        if arena is None:
+            arena, offsets = packing.pack_mimi_encoder(state, num_codebooks, max_positions)
+        off = offsets
+        self.arena = arena.to(self.device)
+        self.num_codebooks = off["num_codebooks"]
+        cfg = MimiEncConfig(self.num_codebooks, off["n_layers"], window, off["max_positions"], int(extra_right))
+        w = MimiEncWeights()
+        for k in ("conv0_w", "conv0_b", "rope", "downsample_w", "codebooks_t", "codebooks", "codebook_sq"):
+            setattr(w, k, off[k])
+        w.in_proj[0], w.in_proj[1] = off["in_proj"]
+        for i, l in enumerate(off["layers"]):
+            for k, v in l.items():
+                setattr(w.layers[i], k, v)
+        for i, cv in enumerate(off["convs"]):
+            for k, v in cv.items():
+                setattr(w.convs[i], k, v)
+        self.c_cfg, self.c_w = cfg, w
+        h = C.c_void_p()
+        check(self.lib.smoltts_mimi_encoder_create(C.byref(cfg), C.byref(w), dptr(self.arena), self.arena.numel(), C.byref(h)),
+              "smoltts_mimi_encoder_create")
+        self.handle = h
+        self._ws = None
+
+    def frames(self, n_samples: int) -> int:
+        return int(self.lib.smoltts_mimi_encode_frames(n_samples))
+
+    def encode(self, pcm, return_aux: bool = False):
+        """pcm: 1-D float array/tensor of 24 kHz samples -> int32 device tensor (num_codebooks, frames)
+        [, latents (frames, 512), squared-distance gaps (num_codebooks, frames)]."""
+        x = torch.as_tensor(pcm, dtype=torch.float32).reshape(-1).to(self.device).contiguous()
+        n = x.numel()
+        if n == 0:
+            raise SmolttsError("encode: empty signal")
+        need = self.lib.smoltts_mimi_encode_workspace_bytes(self.handle, n)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = _alloc_slab(need, self.device)
+        F = self.frames(n)
+        codes = torch.empty(self.num_codebooks, F, dtype=torch.int32, device=self.device)
+        emb = torch.empty(F, 512, dtype=torch.float32, device=self.device) if return_aux else None
+        gap = torch.empty(self.num_codebooks, F, dtype=torch.float32, device=self.device) if return_aux else None
+        check(self.lib.smoltts_mimi_encode(self.handle, dptr(x), n, dptr(codes), dptr(emb) if return_aux else None,
+                                           dptr(gap) if return_aux else None, dptr(self._ws), self._ws.numel(), current_stream_ptr()),
+              "smoltts_mimi_encode")
+        return (codes, emb, gap) if return_aux else codes
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.smoltts_mimi_encoder_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -240,3 +240,76 @@ def pack_mimi(state: Dict[str, torch.Tensor], num_codebooks: int = 8, max_positi
     off["n_layers"] = n_layers
     off["max_positions"] = max_positions
     return ab.finish(), off
+
+
+ENC_RATIOS = (4, 5, 6, 8)
+
+
+def mimi_encoder_conv_specs():
+    """(HF key under encoder.layers, cin, cout, k, stride) in execution order after layer 0
+    (codec/seanet.py:57-90): per ratio the resnet block's two convs and the strided conv, then the final conv."""
+    specs, ch, li = [], 64, 1
+    for r in ENC_RATIOS:
+        specs.append((f"{li}.block.1", ch, ch // 2, 3, 1))
+        specs.append((f"{li}.block.3", ch // 2, ch, 1, 1))
+        specs.append((str(li + 2), ch, 2 * ch, 2 * r, r))
+        ch *= 2
+        li += 3
+    specs.append(("14", 1024, 512, 3, 1))
+    return specs
+
+
+def pack_mimi_encoder(state: Dict[str, torch.Tensor], num_codebooks: int = 8, max_positions: int = 2048):
+    """Arena + offsets (SmolttsMimiEncWeights) of the encode half; ``state`` uses the Hugging Face
+    ``MimiModel.state_dict()`` names (encoder.*, encoder_transformer.*, downsample.*, quantizer.*)."""
+    st = {k: v.float() for k, v in state.items()}
+    ab = ArenaBuilder()
+    f32 = torch.float32
+    off: Dict[str, object] = {}
+    w0 = st["encoder.layers.0.conv.weight"]
+    if tuple(w0.shape) != (64, 1, 7):
+        raise ValueError(f"encoder.layers.0.conv.weight has shape {tuple(w0.shape)}, expected (64, 1, 7)")
+    off["conv0_w"] = ab.add(torch.cat([w0[:, 0, :], torch.zeros(64, 1)], dim=1).contiguous())
+    off["conv0_b"] = ab.add(st["encoder.layers.0.conv.bias"])
+    convs = []
+    for key, cin, cout, k, stride in mimi_encoder_conv_specs():
+        w, b = st[f"encoder.layers.{key}.conv.weight"], st[f"encoder.layers.{key}.conv.bias"]
+        if tuple(w.shape) != (cout, cin, k):
+            raise ValueError(f"encoder.layers.{key}.conv.weight has shape {tuple(w.shape)}, expected {(cout, cin, k)}")
+        gw, gb = conv_as_gemm(w, b, False, stride)
+        convs.append({"w": ab.add(tile_t16x32(gw, f32)), "b": ab.add(gb), "cin": cin, "cout": cout, "k": k, "stride": stride,
+                      "transposed": 0})
+    off["convs"] = convs
+    n_layers = 1 + max(int(k.split(".")[2]) for k in st if k.startswith("encoder_transformer.layers."))
+    layers = []
+    for li in range(n_layers):
+        p = f"encoder_transformer.layers.{li}."
+        wq, wk, wv = (st[p + f"self_attn.{n}_proj.weight"] for n in ("q", "k", "v"))
+        layers.append({
+            "ln1_w": ab.add(st[p + "input_layernorm.weight"]), "ln1_b": ab.add(st[p + "input_layernorm.bias"]),
+            "wqkv": ab.add(tile_t16x32(torch.cat([_perm_heads(wq), _perm_heads(wk), wv]), f32)),
+            "wo": ab.add(tile_t16x32(st[p + "self_attn.o_proj.weight"], f32)),
+            "ls1": ab.add(st[p + "self_attn_layer_scale.scale"]),
+            "ln2_w": ab.add(st[p + "post_attention_layernorm.weight"]), "ln2_b": ab.add(st[p + "post_attention_layernorm.bias"]),
+            "fc1": ab.add(tile_t16x32(st[p + "mlp.fc1.weight"], f32)),
+            "fc2": ab.add(tile_t16x32(st[p + "mlp.fc2.weight"], f32)),
+            "ls2": ab.add(st[p + "mlp_layer_scale.scale"]),
+        })
+    off["layers"] = layers
+    off["rope"] = ab.add(rope_table(max_positions, 64, 10000.0, bf16=False))
+    wd = st["downsample.conv.weight"]  # (512, 512, 4), no bias
+    off["downsample_w"] = ab.add(tile_t16x32(conv_as_gemm(wd, torch.zeros(wd.shape[0]), False, 2)[0], f32))
+    off["in_proj"] = [ab.add(tile_t16x32(st[f"quantizer.{g}_residual_vector_quantizer.input_proj.weight"][:, :, 0].contiguous(), f32))
+                      for g in ("semantic", "acoustic")]
+    books = []
+    for q in range(num_codebooks):
+        grp, li = ("semantic", 0) if q == 0 else ("acoustic", q - 1)
+        p = f"quantizer.{grp}_residual_vector_quantizer.layers.{li}.codebook."
+        books.append(st[p + "embed_sum"] / torch.clamp(st[p + "cluster_usage"], min=1e-5)[:, None])  # rvq.py:41-48
+    off["codebooks_t"] = ab.add(torch.stack([tile_t16x32(b, f32) for b in books]))
+    off["codebooks"] = ab.add(torch.stack(books))
+    off["codebook_sq"] = ab.add(torch.stack([(b * b).sum(-1) for b in books]))
+    off["n_layers"] = n_layers
+    off["max_positions"] = max_positions
+    off["num_codebooks"] = num_codebooks
+    return ab.finish(), off
