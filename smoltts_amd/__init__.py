@@ -44,6 +44,10 @@ class SmolTTS:
         self.lm = LMEngine(config, state, self.token_config, numerics or NumericsMode.torch_reference())
         self.prompt_encoder = PromptEncoder.from_config(tokenizer, config, self.token_config)
         self.codec = MimiEngine(mimi_state, num_codebooks=config.num_codebooks, window=codec_window, max_positions=2 * 1026 + 2)
+        # the encode half (voice-clone prompts) is packed on first use, and only if the checkpoint carries it
+        self._mimi_encoder_state = mimi_state if "encoder.layers.0.conv.weight" in mimi_state else None
+        self._codec_window = codec_window
+        self._encoder = None
         self.sampling_rate = 24_000
 
     # -- prompt (``_get_prompt``, __init__.py:120-151)
@@ -56,14 +60,15 @@ class SmolTTS:
         # the reference façade always uses GenerationSettings() (temp 0.7 / 0.7, __init__.py:77,85)
         return generation_settings or GenerationSettings()
 
-    def generate_codes(self, inputs: List[str], voices: Optional[List[str]] = None, generation_settings=None):
+    def generate_codes(self, inputs: List[str], voices: Optional[List[str]] = None, generation_settings=None, speakers=None):
         """Batched synthesis to audio-code grids: one (n_codebooks, F_b) uint32 array per input."""
         import numpy as np
 
         from .generate import BatchGenerator
 
         voices = voices or ["heart"] * len(inputs)
-        prompts = [self._get_prompt(t, v) for t, v in zip(inputs, voices)]
+        speakers = speakers or [None] * len(inputs)
+        prompts = [self._get_prompt(t, v, sp) for t, v, sp in zip(inputs, voices, speakers)]
         gen = BatchGenerator(self.lm, prompts, self._settings(generation_settings), frames_per_sync=16)
         cols: List[list] = [[] for _ in inputs]
         for row in gen:
@@ -92,10 +97,40 @@ class SmolTTS:
 
     def __call__(self, input: str, voice: Optional[str] = "heart", speaker=None, generation_settings=None):
         """Returns flattened float32 PCM (reference __call__, __init__.py:64-81)."""
-        if speaker is not None:
-            raise NotImplementedError("voice-clone speaker prompts (Mimi encoder) are out of this round's scope")
-        codes = self.generate_codes([input], [voice if voice is not None else "heart"], generation_settings)[0]
+        codes = self.generate_codes([input], [voice if voice is not None else "heart"], generation_settings,
+                                    speakers=None if speaker is None else [speaker])[0]
         return self.decode_codes(codes)
+
+    # -- voice-clone prompts (``create_speaker``, __init__.py:97-118)
+    def encode_audio(self, audio) -> "np.ndarray":
+        """24 kHz mono float PCM (any shape, flattened) -> (n_codebooks, F) uint32 Mimi codes (``codec.encode``)."""
+        import numpy as np
+
+        from .engine import MimiEncoder
+
+        if self._encoder is None:
+            if self._mimi_encoder_state is None:
+                raise ValueError("the Mimi checkpoint has no encoder.* weights: voice-clone prompts need the full kyutai/mimi model")
+            self._encoder = MimiEncoder(self._mimi_encoder_state, num_codebooks=8, window=self._codec_window)
+            self._mimi_encoder_state = None
+        pcm = np.asarray(audio, dtype=np.float32).reshape(-1)
+        return self._encoder.encode(pcm).cpu().numpy().astype(np.uint32)
+
+    def create_speaker(self, samples: List[dict], system_prompt: Optional[str] = None) -> "np.ndarray":
+        """Speaker prompt grid from reference recordings: per sample the user turn with its transcript, then
+        its Mimi codes closed by ``<|im_end|>\\n``; optionally a leading system turn.  Pass the result as
+        ``speaker=`` to ``__call__``."""
+        import numpy as np
+
+        turns = []
+        for sample in samples:
+            if "audio" not in sample or "text" not in sample:
+                raise ValueError(f"Sample must contain both 'text' and 'audio' but got {sample.keys()}")
+            turns.append(self.prompt_encoder.encode_text_turn("user", sample["text"]))
+            turns.append(self.prompt_encoder.encode_vq(self.encode_audio(sample["audio"])[:8, :].astype(np.int64)))
+        if system_prompt is not None:
+            turns = [self.prompt_encoder.encode_text_turn("system", system_prompt), *turns]
+        return np.concatenate(turns, axis=1).astype(np.int32)
 
     def stream(self, input: str, voice: Optional[str] = "heart", generation_settings=None) -> Iterator["np.ndarray"]:
         """Yields one 1920-sample float32 chunk per generated frame, including the terminating
