@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the first-audio-chunk latency measurement")
     ap.add_argument("--no-mimi", action="store_true", help="diagnostic only: skip the Mimi decode (the result line is then not the metric)")
     ap.add_argument("--overlap-mimi", action="store_true", help="run the Mimi chunk decode on its own stream behind an event (measured: no gain, the many-workgroup Mimi kernels delay the latency-bound frame graphs)")
+    ap.add_argument("--mimi-cus", type=int, default=0, help="with --overlap-mimi: restrict the Mimi stream to this many CUs (hipExtStreamCreateWithCUMask)")
+    ap.add_argument("--cu-pattern", default="low", choices=["low", "xcd"], help="which mask bits: the N lowest, or N/32 whole XCDs (bit i -> XCD i mod 8)")
+    ap.add_argument("--lm-complement", action="store_true", help="restrict the frame-graph stream to the CUs the Mimi stream does not use")
     ap.add_argument("--streams", type=int, default=1, help="independent decode streams per GPU (slots are split evenly)")
     args = ap.parse_args()
 
@@ -143,6 +146,32 @@ def main():
     # The Mimi decode of chunk i only needs the codes of chunk i, so it runs on its own stream behind an
     # event and overlaps the (latency-bound, few-CU) frame graphs of chunk i+1.
     mimi_streams = [torch.cuda.Stream(device=dev, priority=0) for _ in range(S)]
+    if args.overlap_mimi and args.mimi_cus > 0:
+        import ctypes
+
+        hip = ctypes.CDLL("libamdhip64.so")
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        words = (n_cu + 31) // 32
+        if args.cu_pattern == "low":
+            bits = [i < args.mimi_cus for i in range(n_cu)]
+        else:
+            bits = [(i % 8) < args.mimi_cus // (n_cu // 8) for i in range(n_cu)]
+
+        def masked_stream(sel, prio):
+            m = (ctypes.c_uint32 * words)()
+            for i, b in enumerate(sel):
+                if b:
+                    m[i // 32] |= 1 << (i % 32)
+            h = ctypes.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), words, m)
+            if rc != 0:
+                raise SystemExit(f"hipExtStreamCreateWithCUMask failed: {rc}")
+            return torch.cuda.ExternalStream(h.value, device=dev)
+
+        mimi_streams = [masked_stream(bits, 0) for _ in range(S)]
+        if args.lm_complement:
+            streams = [masked_stream([not b for b in bits], -1) for _ in range(S)]
+        log(f"CU masks: Mimi stream on {sum(bits)} of {n_cu} CUs ({args.cu_pattern}); frame graphs on {'the complement' if args.lm_complement else 'all'}")
 
     def step(i):
         for j in range(S):

@@ -79,6 +79,9 @@ typedef struct SmolttsLMConfig {
   int32_t semantic_start_id, semantic_end_id, im_end_id;
   int32_t max_seq_len;        /* rows of the slow RoPE table */
   float norm_eps;
+  int32_t weight_format;      /* SMOLTTS_W_BF16 (0) | SMOLTTS_W_FP8 (1): format of every "T16x32" Linear below.
+                                 fp8: each matrix is its e4m3 tiles (rows * K bytes) followed by fp32 row scales
+                                 [rows]; the depthwise head is one such block per step (stride rows * (K + 4) bytes) */
 } SmolttsLMConfig;
 
 typedef struct SmolttsLMWeights {
@@ -311,8 +314,13 @@ int smoltts_k_gemm(const SmolttsGemmArgs* a, void* stream);
  * lane l = 16*q + r the 8 bf16 of piece p of x[16*tile + r][32*chunk + 8q .. +8); the three pieces
  * sum exactly to the fp32 value (already multiplied by the consumer's RMSNorm weight).  Buffer
  * size: ceil(M/16)*16 * K * 6 bytes. */
+enum {  /* weight formats of the DualAR Linears */
+  SMOLTTS_W_BF16 = 0,  /* bf16 T16x32 tiles (1 KiB per 16 rows x 32 columns) */
+  SMOLTTS_W_FP8 = 1    /* fp8 e4m3 (OCP) T16x32 tiles (512 B) + one fp32 scale per output row: w = q * scale */
+};
+
 typedef struct SmolttsGemm3Args {
-  const void* w_dev;           /* bf16 T16x32 [N][K] */
+  const void* w_dev;           /* T16x32 [N][K] in w_format */
   const void* x3_dev;          /* X3 operand [M][K] */
   int32_t M, N, K;
   int32_t epilogue;            /* SMOLTTS_EPI_STORE | _RESID | _SWIGLU | _QKV_ROPE */
@@ -333,6 +341,8 @@ typedef struct SmolttsGemm3Args {
   const float* rope_dev; const int32_t* row_pos_dev; const int32_t* row_slot_dev;
   float* k_cache_dev; float* v_cache_dev;
   int32_t n_q_heads, n_kv_heads, cache_len;
+  int32_t w_format;            /* SMOLTTS_W_BF16 | SMOLTTS_W_FP8 */
+  const float* w_scale_dev;    /* SMOLTTS_W_FP8: [N] row scales; NULL otherwise */
 } SmolttsGemm3Args;
 
 int smoltts_k_gemm3(const SmolttsGemm3Args* a, void* stream);

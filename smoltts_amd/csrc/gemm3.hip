@@ -28,6 +28,7 @@ namespace smoltts {
 
 struct Gemm3Dev {
   const char* w;
+  const float* wscale;  // fp8 weights: per-output-row scale [N]; nullptr = bf16 weights
   const char* x3;
   int M, N, K;
   int half_rows;  // MT == 1 only: a workgroup owns 8 of the tile's 16 rows (twice the workgroups, half the X3 bytes each)
@@ -68,10 +69,38 @@ __device__ __forceinline__ uint4 load_w16(const char* ptr) {
 #endif
 }
 
+// fp8 weights (e4m3, per-row scale applied in the epilogue): a lane's 8 bytes -> the bf16x8 A fragment.
+// e4m3 has 3 mantissa bits, so the upper half of the converted fp32 is the exact bf16.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf16_pair(f32x2_t f) {
+  return (__float_as_uint(f[0]) >> 16) | (__float_as_uint(f[1]) & 0xffff0000u);
+}
+__device__ __forceinline__ bf16x8_t fp8x8_to_bf16x8(uint32_t lo, uint32_t hi) {
+  uint4 o;
+  o.x = bf16_pair(__builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false));
+  o.y = bf16_pair(__builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true));
+  o.z = bf16_pair(__builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false));
+  o.w = bf16_pair(__builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true));
+  return __builtin_bit_cast(bf16x8_t, o);
+}
+template <bool W8>
+__device__ __forceinline__ uint4 load_wfrag(const char* ptr) {  // ptr already includes the lane offset
+  if (W8) {
+    const uint2 v = *reinterpret_cast<const uint2*>(ptr);
+    return make_uint4(v.x, v.y, 0, 0);
+  }
+  return load_w16(ptr);
+}
+template <bool W8>
+__device__ __forceinline__ bf16x8_t wfrag_bf16(uint4 v) {
+  return W8 ? fp8x8_to_bf16x8(v.x, v.y) : __builtin_bit_cast(bf16x8_t, v);
+}
+
 __device__ __forceinline__ float silu3(float x) { return x / (1.f + expf(-x)); }
 
-template <int MT, int T, int U, int EPI>
+template <int MT, int T, int U, int EPI, bool W8>
 __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
+  constexpr int WTILE = W8 ? 512 : 1024, WLANE = W8 ? 8 : 16;  // bytes per weight tile-chunk / per lane
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int nwaves = blockDim.x >> 6;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -104,7 +133,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
   for (int t = 0; t < T; ++t) {
     const int ntile = ng * T + t;
     wv[t] = ntile * 16 < p.N;
-    wb[t] = p.w + (size_t)ntile * nchunks * 1024 + lane * 16;
+    wb[t] = p.w + (size_t)ntile * nchunks * WTILE + lane * WLANE;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
@@ -118,7 +147,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
       const bool cv = c < nchunks;
 #pragma unroll
       for (int t = 0; t < T; ++t)
-        wf[u][t] = (cv && wv[t]) ? load_w16(wb[t] + (size_t)c * 1024) : make_uint4(0, 0, 0, 0);
+        wf[u][t] = (cv && wv[t]) ? load_wfrag<W8>(wb[t] + (size_t)c * WTILE) : make_uint4(0, 0, 0, 0);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -135,7 +164,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
   // kernel waits on nothing
   int pos = 0, slot = 0;
   float ssv[16];
-  float4 rr[T], bb[T], ga[T], gb[T];
+  float4 rr[T], bb[T], ga[T], gb[T], ws[T];
   if (fin) {  // wave-uniform branches, clamped (always valid) addresses: no per-lane control flow
     const int mc = m < p.M ? m : p.M - 1;
     if (kRope) { pos = p.row_pos[mc]; slot = p.row_slot[mc]; }
@@ -156,7 +185,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
       const int n0r = (ng * T + t) * 16 + q * 4;
       const int n0 = n0r < p.N ? n0r : p.N - 4;  // N % 4 == 0
       rr[t] = bb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-      ga[t] = gb[t] = make_float4(1.f, 1.f, 1.f, 1.f);
+      ga[t] = gb[t] = ws[t] = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (W8) ws[t] = *reinterpret_cast<const float4*>(p.wscale + n0);
       if (kResid) rr[t] = *reinterpret_cast<const float4*>(p.resid + (long)mc * p.ldo + n0);
       if (p.bias != nullptr) bb[t] = *reinterpret_cast<const float4*>(p.bias + n0);
       if (kEmits && p.emit.x3a && p.emit.gamma_a) ga[t] = *reinterpret_cast<const float4*>(p.emit.gamma_a + n0);
@@ -169,7 +199,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
     for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        const bf16x8_t a = __builtin_bit_cast(bf16x8_t, wf[u][t]);
+        const bf16x8_t a = wfrag_bf16<W8>(wf[u][t]);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -240,6 +270,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
     const int ntile = ng * T + t;
     const int n0 = ntile * 16 + q * 4;
     const bool valid = mvalid && n0 < p.N;  // N % 4 == 0
+    if (W8) { v[0] *= ws[t].x; v[1] *= ws[t].y; v[2] *= ws[t].z; v[3] *= ws[t].w; }
     v[0] = v[0] * rstd + bb[t].x; v[1] = v[1] * rstd + bb[t].y; v[2] = v[2] * rstd + bb[t].z; v[3] = v[3] * rstd + bb[t].w;
 
     if (EPI == SMOLTTS_EPI_STORE || EPI == SMOLTTS_EPI_RESID) {
@@ -286,8 +317,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
 // B-fragment order) are copied into LDS once per chunk and shared by the 4 waves, each of which holds
 // NTW column tiles and accumulates the whole K itself: no split-K, no cross-wave reduction, the
 // activation operand leaves L2 once per 256 output columns instead of once per 16.
-template <int NTW, int EPI>
+template <int NTW, int EPI, bool W8>
 __global__ __launch_bounds__(256) void gemm3_rows_kernel(Gemm3Dev p) {
+  constexpr int WTILE = W8 ? 512 : 1024, WLANE = W8 ? 8 : 16;
   __shared__ uint4 xs[12 * 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, q = lane >> 4;
@@ -308,7 +340,7 @@ __global__ __launch_bounds__(256) void gemm3_rows_kernel(Gemm3Dev p) {
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     wv[t] = (tile0 + t) * 16 < p.N;
-    wb[t] = p.w + (size_t)(tile0 + t) * nchunks * 1024 + lane * 16;
+    wb[t] = p.w + (size_t)(tile0 + t) * nchunks * WTILE + lane * WLANE;
   }
   f32x4 acc[NTW][4];
 #pragma unroll
@@ -321,7 +353,7 @@ __global__ __launch_bounds__(256) void gemm3_rows_kernel(Gemm3Dev p) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) stage[i] = sp[i] ? *reinterpret_cast<const uint4*>(sp[i] + (size_t)c * 3072) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) wnext[t] = wv[t] ? *reinterpret_cast<const uint4*>(wb[t] + (size_t)c * 1024) : make_uint4(0, 0, 0, 0);
+    for (int t = 0; t < NTW; ++t) wnext[t] = wv[t] ? load_wfrag<W8>(wb[t] + (size_t)c * WTILE) : make_uint4(0, 0, 0, 0);
   };
   fetch(0);
   for (int c = 0; c < nchunks; ++c) {
@@ -330,7 +362,7 @@ __global__ __launch_bounds__(256) void gemm3_rows_kernel(Gemm3Dev p) {
     for (int i = 0; i < 3; ++i) xs[tid + 256 * i] = stage[i];
     bf16x8_t a[NTW];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) a[t] = __builtin_bit_cast(bf16x8_t, wnext[t]);
+    for (int t = 0; t < NTW; ++t) a[t] = wfrag_bf16<W8>(wnext[t]);
     __syncthreads();
     if (c + 1 < nchunks) fetch(c + 1);  // next chunk's loads fly under this chunk's MFMAs
 #pragma unroll
@@ -368,7 +400,12 @@ __global__ __launch_bounds__(256) void gemm3_rows_kernel(Gemm3Dev p) {
       const int n0 = ntile * 16 + q * 4;
       const bool valid = mvalid && n0 < p.N;
       const int n0c = n0 < p.N ? n0 : p.N - 4;
-      float v[4] = {acc[t][mt][0] * rstd, acc[t][mt][1] * rstd, acc[t][mt][2] * rstd, acc[t][mt][3] * rstd};
+      float v[4] = {acc[t][mt][0], acc[t][mt][1], acc[t][mt][2], acc[t][mt][3]};
+      if (W8) {
+        const float4 sc = *reinterpret_cast<const float4*>(p.wscale + n0c);
+        v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+      }
+      v[0] *= rstd; v[1] *= rstd; v[2] *= rstd; v[3] *= rstd;
       if (p.bias) {
         const float4 b = *reinterpret_cast<const float4*>(p.bias + n0c);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -414,56 +451,61 @@ __global__ __launch_bounds__(256) void gemm3_rows_kernel(Gemm3Dev p) {
   }
 }
 
-template <int EPI>
+template <int EPI, bool W8>
 static int launch3_rows(const Gemm3Dev& d, hipStream_t stream) {
   const int ntiles = (d.N + 15) / 16;
   const int NTW = ntiles >= 16 ? 4 : (ntiles >= 8 ? 2 : 1);
   const dim3 grid((ntiles + 4 * NTW - 1) / (4 * NTW), (d.M + 63) / 64);
   ST_REQUIRE(grid.y <= 65535, SMOLTTS_E_INVALID, "gemm3: M=%d too large for one launch", d.M);
-  if (NTW == 4) hipLaunchKernelGGL((gemm3_rows_kernel<4, EPI>), grid, dim3(256), 0, stream, d);
-  else if (NTW == 2) hipLaunchKernelGGL((gemm3_rows_kernel<2, EPI>), grid, dim3(256), 0, stream, d);
-  else hipLaunchKernelGGL((gemm3_rows_kernel<1, EPI>), grid, dim3(256), 0, stream, d);
+  if (NTW == 4) hipLaunchKernelGGL((gemm3_rows_kernel<4, EPI, W8>), grid, dim3(256), 0, stream, d);
+  else if (NTW == 2) hipLaunchKernelGGL((gemm3_rows_kernel<2, EPI, W8>), grid, dim3(256), 0, stream, d);
+  else hipLaunchKernelGGL((gemm3_rows_kernel<1, EPI, W8>), grid, dim3(256), 0, stream, d);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
 }
 
-template <int MT, int T, int U, int EPI>
+template <int MT, int T, int U, int EPI, bool W8>
 static int launch3_one(const Gemm3Dev& d, int nwaves, hipStream_t stream) {
   const int ntiles = (d.N + 15) / 16;
   if (nwaves < MT) nwaves = MT;  // one finishing wave per 16-row tile
   const dim3 grid((ntiles + T - 1) / T, ((d.M + 16 * MT - 1) / (16 * MT)) * (d.half_rows ? 2 : 1));
   const size_t lds = (size_t)nwaves * T * MT * 1024;
-  hipLaunchKernelGGL((gemm3_kernel<MT, T, U, EPI>), grid, dim3(nwaves * 64), lds, stream, d);
+  hipLaunchKernelGGL((gemm3_kernel<MT, T, U, EPI, W8>), grid, dim3(nwaves * 64), lds, stream, d);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
 }
 
 // Decomposition: enough workgroups to spread the weight stream over the chip (16-row tiles go to
 // separate workgroups when there are few column tiles), all of a wave's loads in flight at once.
-template <int EPI>
-static int launch3_epi(const Gemm3Dev& d, hipStream_t stream) {
+template <int EPI, bool W8>
+static int launch3_fmt(const Gemm3Dev& d, hipStream_t stream) {
   const int nchunks = d.K / 32, ntiles = (d.N + 15) / 16;
   int nwaves = (nchunks + 2) / 3;
   nwaves = nwaves < 1 ? 1 : (nwaves > 8 ? 8 : nwaves);  // <= 512 threads: 256 VGPRs per lane
   const int cpw = (nchunks + nwaves - 1) / nwaves;  // chunks per wave
-  if (d.M >= 256) return launch3_rows<EPI>(d, stream);  // prefill: LDS-shared activation chunks, no split-K
+  if (d.M >= 256) return launch3_rows<EPI, W8>(d, stream);  // prefill: LDS-shared activation chunks, no split-K
   if (d.M > 32)  // 33..255 rows: 64 rows per workgroup, weights re-used from registers
-    return launch3_one<4, 1, 2, EPI>(d, nwaves < 4 ? 4 : nwaves, stream);
+    return launch3_one<4, 1, 2, EPI, W8>(d, nwaves < 4 ? 4 : nwaves, stream);
   // 16-row tiles go to separate workgroups (MT = 1); T = the smallest number of column tiles per
   // workgroup that keeps the grid within one workgroup per CU, so every CU takes the activation
   // operand in once and the per-CU byte load (the bound of these kernels) is as even as possible.
   const int row_tiles = (d.M + 15) / 16;
   int T = 1;
   while (T < 4 && ((ntiles + T - 1) / T) * row_tiles > 256) ++T;
-  if (T == 4) return launch3_one<1, 4, 3, EPI>(d, nwaves, stream);
-  if (T == 3) return launch3_one<1, 3, 3, EPI>(d, nwaves, stream);
-  if (T == 2) return launch3_one<1, 2, 3, EPI>(d, nwaves, stream);
+  if (T == 4) return launch3_one<1, 4, 3, EPI, W8>(d, nwaves, stream);
+  if (T == 3) return launch3_one<1, 3, 3, EPI, W8>(d, nwaves, stream);
+  if (T == 2) return launch3_one<1, 2, 3, EPI, W8>(d, nwaves, stream);
   // few column tiles: split the 16-row tiles in two so that ~2x the CUs share the activation bytes
   Gemm3Dev dd = d;
   dd.half_rows = (d.M > 8 && ntiles * row_tiles * 2 <= 256) ? 1 : 0;
-  if (cpw > 6) return launch3_one<1, 1, 12, EPI>(dd, nwaves, stream);
-  if (cpw > 3) return launch3_one<1, 1, 6, EPI>(dd, nwaves, stream);
-  return launch3_one<1, 1, 3, EPI>(dd, nwaves, stream);
+  if (cpw > 6) return launch3_one<1, 1, 12, EPI, W8>(dd, nwaves, stream);
+  if (cpw > 3) return launch3_one<1, 1, 6, EPI, W8>(dd, nwaves, stream);
+  return launch3_one<1, 1, 3, EPI, W8>(dd, nwaves, stream);
+}
+
+template <int EPI>
+static int launch3_epi(const Gemm3Dev& d, hipStream_t stream) {
+  return d.wscale ? launch3_fmt<EPI, true>(d, stream) : launch3_fmt<EPI, false>(d, stream);
 }
 
 unsigned long long* debug_stamp_buffer();  // gemm.hip
@@ -493,7 +535,9 @@ static int launch_gemm3_impl(const SmolttsGemm3Args& a, hipStream_t stream) {
   ST_REQUIRE(a.ssq_in_dev == nullptr || a.K % 64 == 0, SMOLTTS_E_INVALID, "gemm3: normed input needs K %% 64 == 0");
   Gemm3Dev d;
   memset(&d, 0, sizeof(d));
-  d.w = (const char*)a.w_dev; d.x3 = (const char*)a.x3_dev; d.M = a.M; d.N = a.N; d.K = a.K;
+  ST_REQUIRE((a.w_format == SMOLTTS_W_BF16 && !a.w_scale_dev) || (a.w_format == SMOLTTS_W_FP8 && a.w_scale_dev && a.N % 16 == 0),
+             SMOLTTS_E_INVALID, "gemm3: w_format %d / w_scale_dev inconsistent (fp8 needs scales and N %% 16 == 0)", a.w_format);
+  d.w = (const char*)a.w_dev; d.wscale = a.w_scale_dev; d.x3 = (const char*)a.x3_dev; d.M = a.M; d.N = a.N; d.K = a.K;
   d.ssq_in = a.ssq_in_dev; d.eps = a.eps; d.bias = a.bias_dev; d.resid = a.resid_dev; d.out = a.out_dev; d.ldo = a.ldo;
   d.x3_out = (char*)a.x3_out_dev;
   d.emit.x3a = (char*)a.emit_a_dev; d.emit.gamma_a = a.gamma_a_dev; d.emit.x3b = (char*)a.emit_b_dev;

@@ -164,10 +164,13 @@ __global__ void commit_kernel(int B, int H, int max_frames, int im_end, int stop
   if ((stop_on_eos && new_col[b * H] == im_end) || f + 1 >= max_frames) done[b] = 1;
 }
 
-SmolttsGemm3Args base3(const void* w, const void* x3, int M, int N, int K, int epilogue) {
+// `fmt` = the engine's weight_format; an fp8 matrix is its tiles (N*K bytes, N % 16 == 0) followed by N row scales
+SmolttsGemm3Args base3(int fmt, const void* w, const void* x3, int M, int N, int K, int epilogue) {
   SmolttsGemm3Args a;
   memset(&a, 0, sizeof(a));
   a.w_dev = w; a.x3_dev = x3; a.M = M; a.N = N; a.K = K; a.epilogue = epilogue;
+  a.w_format = fmt;
+  if (fmt == SMOLTTS_W_FP8) a.w_scale_dev = reinterpret_cast<const float*>(static_cast<const char*>(w) + (size_t)N * K);
   return a;
 }
 
@@ -180,7 +183,7 @@ int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, i
   const char* A = e->arena;
   const float eps = e->cfg.norm_eps;
   {  // RMSNorm scale + QKV + RoPE + cache write
-    SmolttsGemm3Args a = base3(A + bw.wqkv, in_x3, M, (n_head + 2 * n_kv) * 64, dim, SMOLTTS_EPI_QKV_ROPE);
+    SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.wqkv, in_x3, M, (n_head + 2 * n_kv) * 64, dim, SMOLTTS_EPI_QKV_ROPE);
     a.ssq_in_dev = s->ssq; a.eps = eps; a.out_dev = q; a.ldo = n_head * 64;
     a.rope_dev = rope; a.row_pos_dev = row_pos; a.row_slot_dev = row_slot;
     a.k_cache_dev = kc; a.v_cache_dev = vc; a.n_q_heads = n_head; a.n_kv_heads = n_kv; a.cache_len = cache_len;
@@ -188,18 +191,18 @@ int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, i
   }
   ST_TRY(launch_attention(q, kc, vc, row_pos, row_slot, M, n_head, n_kv, cache_len, 0, nullptr, s->x3a, st));
   {  // x += attn . Wo^T ; publish x * ffn_norm for w1|w3
-    SmolttsGemm3Args a = base3(A + bw.wo, s->x3a, M, dim, dim, SMOLTTS_EPI_RESID);
+    SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.wo, s->x3a, M, dim, dim, SMOLTTS_EPI_RESID);
     a.resid_dev = x; a.out_dev = x; a.ldo = dim;
     a.emit_a_dev = s->x3n; a.gamma_a_dev = (const float*)(A + bw.ffn_norm); a.ssq_out_dev = s->ssq;
     ST_TRY(launch_gemm3(a, st));
   }
   {  // h = silu(w1 n) * (w3 n), n = RMSNorm(x); written as w2's operand
-    SmolttsGemm3Args a = base3(A + bw.w13, s->x3n, M, 2 * inter, dim, SMOLTTS_EPI_SWIGLU);
+    SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.w13, s->x3n, M, 2 * inter, dim, SMOLTTS_EPI_SWIGLU);
     a.ssq_in_dev = s->ssq; a.eps = eps; a.x3_out_dev = s->x3h;
     ST_TRY(launch_gemm3(a, st));
   }
   {  // x += h . W2^T ; publish for the next consumer(s)
-    SmolttsGemm3Args a = base3(A + bw.w2, s->x3h, M, dim, inter, SMOLTTS_EPI_RESID);
+    SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.w2, s->x3h, M, dim, inter, SMOLTTS_EPI_RESID);
     a.resid_dev = x; a.out_dev = x; a.ldo = dim;
     a.emit_a_dev = next.x3a; a.gamma_a_dev = next.gamma_a; a.emit_b_dev = next.x3b; a.gamma_b_dev = next.gamma_b;
     a.ssq_out_dev = next.ssq;
@@ -236,7 +239,7 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
   const char* A = e->arena;
   const int B = s->B, H = 1 + c.n_fast;
   {  // logits = RMSNorm(x) . E^T   (lm/rq_transformer.py:184-189)
-    SmolttsGemm3Args a = base3(A + e->w.head, s->x3n, B, c.vocab_size, c.dim, SMOLTTS_EPI_STORE);
+    SmolttsGemm3Args a = base3(c.weight_format, A + e->w.head, s->x3n, B, c.vocab_size, c.dim, SMOLTTS_EPI_STORE);
     a.ssq_in_dev = s->ssq; a.eps = c.norm_eps; a.out_dev = s->logits; a.ldo = c.vocab_size;
     ST_TRY(launch_gemm3(a, st));
   }
@@ -247,7 +250,7 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
   const char* first_x3 = s->x3n2;
   const EmitArgs to_fast0{s->x3n, gamma_at(e, e->w.fast_layers[0].attn_norm), nullptr, nullptr, s->ssq};
   if (c.has_fast_project_in) {  // Linear(dim, fast_dim) with bias (modeling :339-342)
-    SmolttsGemm3Args a = base3(A + e->w.fast_proj_w, s->x3n2, B, c.fast_dim, c.dim, SMOLTTS_EPI_STORE);
+    SmolttsGemm3Args a = base3(c.weight_format, A + e->w.fast_proj_w, s->x3n2, B, c.fast_dim, c.dim, SMOLTTS_EPI_STORE);
     a.bias_dev = (const float*)(A + e->w.fast_proj_b); a.out_dev = s->xf; a.ldo = c.fast_dim;
     a.emit_a_dev = to_fast0.x3a; a.gamma_a_dev = to_fast0.gamma_a; a.ssq_out_dev = s->ssq;
     ST_TRY(launch_gemm3(a, st));
@@ -266,7 +269,8 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
     }
     {  // fast_norm + depthwise head slice i  (lm/rq_transformer.py:209-217)
       const size_t wrow = (size_t)i * e->w.fast_head_step_stride;  // rows; a row tile is 16 rows
-      SmolttsGemm3Args a = base3(A + e->w.fast_head + wrow * c.fast_dim * 2, s->x3n, B, c.codebook_size, c.fast_dim, SMOLTTS_EPI_STORE);
+      const size_t wbytes = c.weight_format == SMOLTTS_W_FP8 ? wrow * (c.fast_dim + 4) : wrow * c.fast_dim * 2;
+      SmolttsGemm3Args a = base3(c.weight_format, A + e->w.fast_head + wbytes, s->x3n, B, c.codebook_size, c.fast_dim, SMOLTTS_EPI_STORE);
       a.ssq_in_dev = s->ssq; a.eps = c.norm_eps; a.out_dev = s->logits; a.ldo = c.codebook_size;
       ST_TRY(launch_gemm3(a, st));
     }
@@ -323,21 +327,30 @@ int run_decode_frame(SmolttsSession* s, hipStream_t st) {
 
 int check_offsets(const SmolttsLMConfig& c, const SmolttsLMWeights& w, size_t bytes) {
   auto ok = [&](uint64_t off, size_t need) { return off % 16 == 0 && off + need <= bytes; };
+  ST_REQUIRE(c.weight_format == SMOLTTS_W_BF16 || c.weight_format == SMOLTTS_W_FP8, SMOLTTS_E_INVALID,
+             "engine: unknown weight_format %d", c.weight_format);
+  const bool f8 = c.weight_format == SMOLTTS_W_FP8;
+  // bytes of one Linear [rows][k]: bf16 tiles, or e4m3 tiles + fp32 row scales
+  auto mat = [&](size_t rows, size_t k) { return f8 ? rows * (k + 4) : rows * k * 2; };
   const size_t d = c.dim, fd = c.fast_dim;
-  ST_REQUIRE(ok(w.text_emb, (size_t)c.vocab_size * d * 2) && ok(w.head, (size_t)c.vocab_size * d * 2) &&
+  if (f8)
+    ST_REQUIRE(c.vocab_size % 16 == 0 && c.codebook_size % 16 == 0, SMOLTTS_E_INVALID, "engine: fp8 weights need vocab and codebook sizes %% 16 == 0");
+  ST_REQUIRE(ok(w.text_emb, (size_t)c.vocab_size * d * 2) && ok(w.head, mat(c.vocab_size, d)) &&
                  ok(w.codebook_emb, (size_t)c.codebook_size * c.num_codebooks * d * 2) && ok(w.norm, d * 4) &&
                  ok(w.fast_norm, fd * 4) && ok(w.rope, (size_t)c.max_seq_len * 64 * 4) && ok(w.fast_rope, (size_t)c.n_fast * 64 * 4),
              SMOLTTS_E_INVALID, "engine: weight offsets outside the arena or misaligned");
   const size_t head_rows = (size_t)(c.n_fast - 1) * w.fast_head_step_stride + c.codebook_size;
-  ST_REQUIRE(ok(w.fast_head, head_rows * fd * 2), SMOLTTS_E_INVALID, "engine: fast_head outside the arena");
+  ST_REQUIRE(ok(w.fast_head, mat(head_rows, fd)), SMOLTTS_E_INVALID, "engine: fast_head outside the arena");
   ST_REQUIRE(w.fast_head_step_stride % 16 == 0, SMOLTTS_E_INVALID, "engine: fast_head_step_stride must be a multiple of 16");
+  if (c.has_fast_project_in)
+    ST_REQUIRE(ok(w.fast_proj_w, mat(fd, d)) && ok(w.fast_proj_b, fd * 4), SMOLTTS_E_INVALID, "engine: fast_project_in outside the arena");
   for (int l = 0; l < c.n_layer + c.n_fast_layer; ++l) {
     const bool fast = l >= c.n_layer;
     const SmolttsBlockWeights& b = fast ? w.fast_layers[l - c.n_layer] : w.layers[l];
     const size_t dd = fast ? fd : d, hh = fast ? c.fast_n_head : c.n_head, kk = fast ? c.fast_n_kv_head : c.n_kv_head;
     const size_t ii = fast ? c.fast_inter : c.inter;
-    ST_REQUIRE(ok(b.attn_norm, dd * 4) && ok(b.ffn_norm, dd * 4) && ok(b.wqkv, (hh + 2 * kk) * 64 * dd * 2) &&
-                   ok(b.wo, dd * dd * 2) && ok(b.w13, 2 * ii * dd * 2) && ok(b.w2, dd * ii * 2),
+    ST_REQUIRE(ok(b.attn_norm, dd * 4) && ok(b.ffn_norm, dd * 4) && ok(b.wqkv, mat((hh + 2 * kk) * 64, dd)) &&
+                   ok(b.wo, mat(dd, dd)) && ok(b.w13, mat(2 * ii, dd)) && ok(b.w2, mat(dd, ii)),
                SMOLTTS_E_INVALID, "engine: layer %d weight offsets outside the arena or misaligned", l);
   }
   return SMOLTTS_OK;

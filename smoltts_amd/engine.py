@@ -35,7 +35,7 @@ class LMConfig(C.Structure):
         "fast_dim", "n_fast_layer", "fast_n_head", "fast_n_kv_head", "fast_inter",
         "vocab_size", "codebook_size", "num_codebooks", "n_fast", "duplicate_code_0", "depthwise_wte",
         "has_fast_project_in", "embed_mask_mode", "semantic_start_id", "semantic_end_id", "im_end_id",
-        "max_seq_len")] + [("norm_eps", C.c_float)]
+        "max_seq_len")] + [("norm_eps", C.c_float), ("weight_format", C.c_int32)]
 
 
 class LMWeights(C.Structure):
@@ -195,7 +195,7 @@ def _alloc_slab(nbytes: int, device) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------- LM engine
-def lm_config_struct(cfg: RQTransformerModelArgs, tok: TokenConfig, numerics: NumericsMode) -> LMConfig:
+def lm_config_struct(cfg: RQTransformerModelArgs, tok: TokenConfig, numerics: NumericsMode, weight_format: int = 0) -> LMConfig:
     c = LMConfig()
     c.dim, c.n_layer, c.n_head, c.n_kv_head, c.inter = cfg.dim, cfg.n_layer, cfg.n_head, cfg.n_local_heads, cfg.intermediate_size
     c.fast_dim, c.n_fast_layer, c.fast_n_head = cfg.fast_dim, cfg.n_fast_layer, cfg.fast_n_head
@@ -211,6 +211,7 @@ def lm_config_struct(cfg: RQTransformerModelArgs, tok: TokenConfig, numerics: Nu
     c.im_end_id = tok.im_end_id
     c.max_seq_len = cfg.max_seq_len
     c.norm_eps = cfg.norm_eps
+    c.weight_format = int(weight_format)
     return c
 
 
@@ -223,17 +224,21 @@ class LMEngine:
     """Immutable model on one GPU: packed weight arena + ``SmolttsEngine`` handle."""
 
     def __init__(self, cfg: RQTransformerModelArgs, state: Dict[str, torch.Tensor], token_config: TokenConfig,
-                 numerics: Optional[NumericsMode] = None, arena: Optional[torch.Tensor] = None, offsets=None):
+                 numerics: Optional[NumericsMode] = None, arena: Optional[torch.Tensor] = None, offsets=None,
+                 weight_format: str = "bf16"):
+        """``weight_format="fp8"``: the Linears are stored as e4m3 with per-row scales (half the weight bytes);
+        the model computed is exactly ``packing.fp8_reference_state`` of the checkpoint."""
         cfg.validate_for_engine()
         self.lib = load_library()
         self.device = _require_gpu()
         self.cfg, self.token_config = cfg, token_config
         self.numerics = numerics or NumericsMode.torch_reference()
         if arena is None:
-            arena, offsets = packing.pack_lm(cfg, state, self.numerics)
+            arena, offsets = packing.pack_lm(cfg, state, self.numerics, weight_format)
         self.offsets = offsets
+        self.weight_format = "fp8" if offsets.get("weight_format", 0) else "bf16"
         self.arena = arena.to(self.device) if arena.device != self.device else arena
-        self.c_cfg = lm_config_struct(cfg, token_config, self.numerics)
+        self.c_cfg = lm_config_struct(cfg, token_config, self.numerics, offsets.get("weight_format", 0))
         w = LMWeights()
         for k in ("text_emb", "codebook_emb", "fast_emb", "norm", "head", "fast_norm", "fast_head",
                   "fast_head_step_stride", "fast_proj_w", "fast_proj_b", "rope", "fast_rope"):

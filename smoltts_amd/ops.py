@@ -136,8 +136,16 @@ class Gemm3Args(C.Structure):
         ("emit_a_dev", C.c_void_p), ("gamma_a_dev", C.c_void_p), ("emit_b_dev", C.c_void_p), ("gamma_b_dev", C.c_void_p),
         ("ssq_out_dev", C.c_void_p), ("rope_dev", C.c_void_p), ("row_pos_dev", C.c_void_p), ("row_slot_dev", C.c_void_p),
         ("k_cache_dev", C.c_void_p), ("v_cache_dev", C.c_void_p), ("n_q_heads", C.c_int32), ("n_kv_heads", C.c_int32),
-        ("cache_len", C.c_int32),
+        ("cache_len", C.c_int32), ("w_format", C.c_int32), ("w_scale_dev", C.c_void_p),
     ]
+
+
+def pack_weight_fp8(w: torch.Tensor):
+    """Row-major [N, K] -> (e4m3 T16x32 tiles, fp32 row scales) on the current GPU, and the dequantised matrix."""
+    from .packing import quantize_fp8_rows
+
+    q, scale = quantize_fp8_rows(w.detach().float().cpu())
+    return tile_t16x32(q, torch.float8_e4m3fn).view(torch.uint8).cuda(), scale.cuda(), q.float() * scale[:, None]
 
 
 def linear3(x3: torch.Tensor, w_tiles: torch.Tensor, M: int, N: int, K: int, *, epilogue: int = E.EPI_STORE,
@@ -146,8 +154,9 @@ def linear3(x3: torch.Tensor, w_tiles: torch.Tensor, M: int, N: int, K: int, *, 
             emit_a: Optional[torch.Tensor] = None, gamma_a: Optional[torch.Tensor] = None,
             emit_b: Optional[torch.Tensor] = None, gamma_b: Optional[torch.Tensor] = None,
             ssq_out: Optional[torch.Tensor] = None, rope=None, row_pos=None, row_slot=None, k_cache=None, v_cache=None,
-            n_q_heads: int = 0, n_kv_heads: int = 0, cache_len: int = 0):
-    """The bf16-MFMA GEMM over an X3 operand; returns the fp32 ``out`` tensor (None for SWIGLU)."""
+            n_q_heads: int = 0, n_kv_heads: int = 0, cache_len: int = 0, w_scale: Optional[torch.Tensor] = None):
+    """The bf16-MFMA GEMM over an X3 operand; returns the fp32 ``out`` tensor (None for SWIGLU).
+    ``w_scale`` given: ``w_tiles`` are e4m3 tiles (``pack_weight_fp8``)."""
     lib = E.load_library()
     lib.smoltts_k_gemm3.argtypes = [C.POINTER(Gemm3Args), C.c_void_p]
     if out is None and epilogue != E.EPI_SWIGLU:
@@ -164,5 +173,6 @@ def linear3(x3: torch.Tensor, w_tiles: torch.Tensor, M: int, N: int, K: int, *, 
     a.rope_dev, a.row_pos_dev, a.row_slot_dev = E.dptr(rope), E.dptr(row_pos), E.dptr(row_slot)
     a.k_cache_dev, a.v_cache_dev = E.dptr(k_cache), E.dptr(v_cache)
     a.n_q_heads, a.n_kv_heads, a.cache_len = n_q_heads, n_kv_heads, cache_len
+    a.w_format, a.w_scale_dev = (1, E.dptr(w_scale)) if w_scale is not None else (0, None)
     E.check(lib.smoltts_k_gemm3(C.byref(a), E.current_stream_ptr()), "smoltts_k_gemm3")
     return out

@@ -31,13 +31,40 @@ def tile_t16x32(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     if Np != N:
         w = torch.cat([w, torch.zeros(Np - N, K, dtype=w.dtype)], dim=0)
     w = w.to(dtype)
-    if dtype == torch.bfloat16:
+    if dtype == torch.float8_e4m3fn:  # same lane order as bf16, one byte per element (512-byte tiles)
+        w = w.view(torch.uint8)
+    if dtype in (torch.bfloat16, torch.float8_e4m3fn):
         t = w.reshape(Np // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4)  # nt, kc, q, r, 8
     elif dtype == torch.float32:
         t = w.reshape(Np // 16, 16, K // 32, 4, 2, 4).permute(0, 2, 4, 3, 1, 5)  # nt, kc, h, q, r, 4
     else:
         raise ValueError(dtype)
     return t.contiguous().reshape(-1)
+
+
+FP8_MAX = 448.0  # largest finite e4m3 (OCP "fn") value
+
+
+def quantize_fp8_rows(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Row-major [N][K] -> (e4m3 codes [N][K], fp32 scale [N]) with w ~= codes * scale[:, None]; the row
+    maximum maps to 448 (round to nearest even, as ``Tensor.to(float8_e4m3fn)`` does)."""
+    w = w.float()
+    amax = w.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / FP8_MAX, torch.ones_like(amax))
+    return (w / scale[:, None]).to(torch.float8_e4m3fn), scale
+
+
+def dequantize_fp8_rows(w: torch.Tensor) -> torch.Tensor:
+    q, scale = quantize_fp8_rows(w)
+    return q.float() * scale[:, None]
+
+
+def fp8_block(w: torch.Tensor) -> torch.Tensor:
+    """One Linear in SMOLTTS_W_FP8 form: the e4m3 tiles followed by the fp32 row scales (bytes)."""
+    if w.shape[0] % 16:
+        raise ValueError(f"fp8 weights need N % 16 == 0, got {tuple(w.shape)}")
+    q, scale = quantize_fp8_rows(w)
+    return torch.cat([tile_t16x32(q, torch.float8_e4m3fn).view(torch.uint8), scale.contiguous().view(torch.uint8)])
 
 
 def untile_t16x32(flat: torch.Tensor, N: int, K: int) -> torch.Tensor:
@@ -91,12 +118,41 @@ def _wqkv(st, prefix):
     return torch.cat([st[prefix + f"attention.{n}.weight"] for n in ("wq", "wk", "wv")])
 
 
-def pack_lm(cfg: RQTransformerModelArgs, state: Dict[str, torch.Tensor], numerics: NumericsMode):
-    """-> (arena uint8 CPU tensor, offsets dict). Matrices/embeddings are stored as bf16."""
+def fp8_reference_state(cfg: RQTransformerModelArgs, state: Dict[str, torch.Tensor]):
+    """The model the fp8 engine computes, as an ordinary checkpoint: every Linear (wqkv, wo, w1, w3, w2, both
+    heads, fast_project_in) replaced by its dequantised e4m3 values; embedding *lookups* stay bf16, so a tied
+    head becomes an explicit ``output.weight``.  -> (config with tie_word_embeddings=False, state)."""
+    import dataclasses
+
+    st = {k: v.float() for k, v in _clean(state).items()}
+    out = dict(st)
+    for k, v in st.items():
+        if k.endswith((".wqkv.weight", ".wq.weight", ".wk.weight", ".wv.weight", ".wo.weight", ".w1.weight", ".w2.weight", ".w3.weight")) \
+                or k in ("output.weight", "fast_project_in.weight"):
+            out[k] = dequantize_fp8_rows(v)
+    if cfg.tie_word_embeddings:
+        out["output.weight"] = dequantize_fp8_rows(st["embeddings.weight"])
+    fo = st["fast_output.weight"]
+    if fo.dim() == 3:  # (n, d, cs): rows of the GEMM are W[i].T
+        n, d, cs = fo.shape
+        out["fast_output.weight"] = dequantize_fp8_rows(fo.permute(0, 2, 1).reshape(n * cs, d)).reshape(n, cs, d).permute(0, 2, 1).contiguous()
+    else:
+        out["fast_output.weight"] = dequantize_fp8_rows(fo)
+    return dataclasses.replace(cfg, tie_word_embeddings=False), out
+
+
+def pack_lm(cfg: RQTransformerModelArgs, state: Dict[str, torch.Tensor], numerics: NumericsMode, weight_format: str = "bf16"):
+    """-> (arena uint8 CPU tensor, offsets dict).  Embedding tables are bf16; the Linears are bf16 T16x32
+    tiles, or with ``weight_format="fp8"`` e4m3 tiles + per-row scales (``fp8_block``)."""
+    if weight_format not in ("bf16", "fp8"):
+        raise ValueError(weight_format)
     st = _clean(state)
     ab = ArenaBuilder()
     bf = torch.bfloat16
-    off: Dict[str, object] = {}
+    off: Dict[str, object] = {"weight_format": 1 if weight_format == "fp8" else 0}
+
+    def mat(w):  # one Linear [N][K] in the engine's weight format
+        return fp8_block(w) if weight_format == "fp8" else tile_t16x32(w, bf)
 
     def f32(k):
         return st[k].float()
@@ -106,11 +162,11 @@ def pack_lm(cfg: RQTransformerModelArgs, state: Dict[str, torch.Tensor], numeric
         w13 = torch.stack([w1.float(), w3.float()], dim=1).reshape(2 * w1.shape[0], w1.shape[1])
         return {
             "attn_norm": ab.add(f32(prefix + "attention_norm.weight")),
-            "wqkv": ab.add(tile_t16x32(_wqkv(st, prefix).float(), bf)),
-            "wo": ab.add(tile_t16x32(f32(prefix + "attention.wo.weight"), bf)),
+            "wqkv": ab.add(mat(_wqkv(st, prefix).float())),
+            "wo": ab.add(mat(f32(prefix + "attention.wo.weight"))),
             "ffn_norm": ab.add(f32(prefix + "ffn_norm.weight")),
-            "w13": ab.add(tile_t16x32(w13, bf)),
-            "w2": ab.add(tile_t16x32(f32(prefix + "feed_forward.w2.weight"), bf)),
+            "w13": ab.add(mat(w13)),
+            "w2": ab.add(mat(f32(prefix + "feed_forward.w2.weight"))),
         }
 
     emb = f32("embeddings.weight")
@@ -119,7 +175,7 @@ def pack_lm(cfg: RQTransformerModelArgs, state: Dict[str, torch.Tensor], numeric
     off["fast_emb"] = ab.add(f32("fast_embeddings.weight").to(bf))
     off["norm"] = ab.add(f32("norm.weight"))
     head = emb if cfg.tie_word_embeddings else f32("output.weight")
-    off["head"] = ab.add(tile_t16x32(head, bf))
+    off["head"] = ab.add(mat(head))
     off["fast_norm"] = ab.add(f32("fast_norm.weight"))
     fo = f32("fast_output.weight")
     n_fast, cs, fd = cfg.max_fast_seqlen, cfg.codebook_size, cfg.fast_dim
@@ -133,9 +189,12 @@ def pack_lm(cfg: RQTransformerModelArgs, state: Dict[str, torch.Tensor], numeric
         if fo.shape != (cs, fd):
             raise ValueError(f"fast_output.weight has shape {tuple(fo.shape)}")
         off["fast_head_step_stride"] = 0
-    off["fast_head"] = ab.add(tile_t16x32(fo, bf))
+    if weight_format == "fp8" and cfg.depthwise_output:  # one block per depth step so that each carries its own scales
+        off["fast_head"] = ab.add(torch.cat([fp8_block(fo[i * cs:(i + 1) * cs]) for i in range(n_fast)]))
+    else:
+        off["fast_head"] = ab.add(mat(fo))
     if cfg.fast_dim != cfg.dim:
-        off["fast_proj_w"] = ab.add(tile_t16x32(f32("fast_project_in.weight"), bf))
+        off["fast_proj_w"] = ab.add(mat(f32("fast_project_in.weight")))
         off["fast_proj_b"] = ab.add(f32("fast_project_in.bias"))
     else:
         off["fast_proj_w"] = off["fast_proj_b"] = 0

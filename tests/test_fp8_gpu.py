@@ -1,0 +1,149 @@
+"""fp8 (e4m3 + per-row scale) weights — BASELINE config 5.  The engine must compute exactly the model whose
+Linears are the dequantised e4m3 values (packing.fp8_reference_state): products stay exact (3 mantissa bits x
+bf16 pieces), so parity with the oracle on that model is held to the same bar as bf16."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    from smoltts_amd import engine
+
+    engine.load_library()
+    return engine
+
+
+@pytest.fixture(scope="module")
+def ops(E):
+    from smoltts_amd import ops
+
+    return ops
+
+
+def rel_err(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def rms_norm_ref(x, g, eps):
+    return x * torch.rsqrt((x * x).mean(-1, keepdim=True) + eps) * g
+
+
+def test_fp8_codes_are_ocp_e4m3(E, ops):
+    """Every finite e4m3 code through the device conversion == torch.float8_e4m3fn's value."""
+    codes = torch.arange(256, dtype=torch.uint8)
+    vals = codes.view(torch.float8_e4m3fn).float()
+    finite = torch.isfinite(vals)
+    K = 32
+    w = torch.zeros(256, K)
+    w[:, 0] = torch.where(finite, vals, torch.zeros(()))
+    wt, ws, wdq = ops.pack_weight_fp8(w)
+    # rows whose maximum is v: the quantiser maps it to 448 * sign; check the dequantised value instead
+    x = torch.zeros(16, K); x[:, 0] = 1.0
+    x3, _, _ = ops.x3_pack(x.cuda())
+    out = ops.linear3(x3, wt, 16, 256, K, w_scale=ws).cpu()
+    assert torch.equal(out[0], wdq[:, 0])
+    assert rel_err(wdq[:, 0], w[:, 0]) < 1e-6  # a lone value per row is represented exactly (it becomes +-448 * scale)
+    # now a row holding all positive finite codes at once, scale 1: exercises every code point
+    pos = vals[finite & (vals >= 0)]
+    n = pos.numel()
+    Kp = (n + 31) // 32 * 32
+    w2 = torch.zeros(16, Kp); w2[0, :n] = pos  # max = 448 -> scale exactly 1
+    wt2, ws2, wdq2 = ops.pack_weight_fp8(w2)
+    assert float(ws2[0]) == 1.0 and torch.equal(wdq2[0], w2[0])
+    eye = torch.zeros(Kp, Kp); eye[torch.arange(Kp), torch.arange(Kp)] = 1.0
+    x3e, _, _ = ops.x3_pack(eye.cuda())
+    got = ops.linear3(x3e, wt2, Kp, 16, Kp, w_scale=ws2).cpu()  # got[k, 0] = w2[0, k]
+    assert torch.equal(got[:, 0], w2[0])
+
+
+@pytest.mark.parametrize("M", [7, 32, 100, 300])
+def test_fp8_gemm_epilogues(E, ops, M):
+    from smoltts_amd.packing import rope_table
+
+    g = torch.Generator().manual_seed(M)
+    K, I = 768, 1024
+    x = torch.randn(M, K, generator=g)
+    gamma = 1 + 0.1 * torch.randn(K, generator=g)
+    n = rms_norm_ref(x, gamma, 1e-5)
+    x3, _, ssq = ops.x3_pack(x.cuda(), gamma.cuda())
+    # STORE with the RMSNorm row scale (head)
+    wt, ws, wd = ops.pack_weight_fp8(torch.randn(2368, K, generator=g) * 0.04)
+    out = ops.linear3(x3, wt, M, 2368, K, ssq_in=ssq, w_scale=ws)
+    assert rel_err(out.cpu(), n @ wd.T) < 3e-5
+    # SWIGLU
+    w13 = torch.randn(2 * I, K, generator=g) * 0.04
+    wt, ws, wd = ops.pack_weight_fp8(w13)
+    hout = ops.x3_alloc(M, I)
+    ops.linear3(x3, wt, M, 2 * I, K, epilogue=E.EPI_SWIGLU, ssq_in=ssq, x3_out=hout, w_scale=ws)
+    y = n @ wd.T
+    ref_h = F.silu(y[:, 0::2]) * y[:, 1::2]
+    assert rel_err(ops.x3_to_float(hout, M, I), ref_h) < 3e-5
+    # RESID + emission from the SwiGLU product (w2)
+    wt, ws, wd = ops.pack_weight_fp8(torch.randn(K, I, generator=g) * 0.03)
+    r = torch.randn(M, K, generator=g)
+    rd = r.cuda()
+    ea = ops.x3_alloc(M, K)
+    so = torch.zeros(M, K // 16).cuda()
+    ops.linear3(hout, wt, M, K, I, epilogue=E.EPI_RESID, resid=rd, out=rd, emit_a=ea, gamma_a=gamma.cuda(), ssq_out=so, w_scale=ws)
+    ref = r + ref_h @ wd.T
+    assert rel_err(rd.cpu(), ref) < 3e-5
+    assert rel_err(ops.x3_to_float(ea, M, K), rd.cpu() * gamma) < 1e-6
+    # QKV + RoPE + cache scatter
+    Hq, Hkv, slots, cache_len = 12, 4, 8, 64
+    N = (Hq + 2 * Hkv) * 64
+    wt, ws, wd = ops.pack_weight_fp8(torch.randn(N, K, generator=g) * 0.04)
+    rope = rope_table(cache_len, 64, 100000.0, bf16=True)
+    pairs = torch.randperm(slots * cache_len, generator=g)[:M]
+    row_slot, row_pos = (pairs // cache_len).int(), (pairs % cache_len).int()
+    kc, vc = torch.zeros(slots, Hkv, cache_len, 64).cuda(), torch.zeros(slots, Hkv, cache_len, 64).cuda()
+    out = ops.linear3(x3, wt, M, N, K, epilogue=E.EPI_QKV_ROPE, ssq_in=ssq, rope=rope.cuda(), row_pos=row_pos.cuda(), row_slot=row_slot.cuda(),
+                      k_cache=kc, v_cache=vc, n_q_heads=Hq, n_kv_heads=Hkv, cache_len=cache_len, w_scale=ws)
+    q, k, v = (n @ wd.T).split([Hq * 64, Hkv * 64, Hkv * 64], dim=-1)
+    cs = rope[row_pos.long()][:, None]
+
+    def rot(t):
+        ts = t.reshape(*t.shape[:-1], -1, 2)
+        return torch.stack([ts[..., 0] * cs[..., 0] - ts[..., 1] * cs[..., 1], ts[..., 1] * cs[..., 0] + ts[..., 0] * cs[..., 1]], -1).flatten(-2)
+
+    assert rel_err(out.cpu(), rot(q.view(M, Hq, 64)).reshape(M, -1)) < 3e-5
+    assert rel_err(kc.cpu()[row_slot.long(), :, row_pos.long()], rot(k.view(M, Hkv, 64))) < 3e-5
+    assert rel_err(vc.cpu()[row_slot.long(), :, row_pos.long()], v.view(M, Hkv, 64)) < 3e-5
+
+
+@pytest.mark.parametrize("cfgname,B,frames", [("tiny", 5, 16), ("tiny_proj", 3, 12), ("tiny_nodup", 3, 12), ("smoltts_byte_150m", 8, 5)])
+def test_fp8_engine_matches_oracle_on_dequantised_model(cfgname, B, frames):
+    from oracle.lm_oracle import LMOracle, OracleLMConfig
+    from smoltts_amd.config import NumericsMode, TokenConfig
+    from smoltts_amd.engine import LMEngine, LMSession
+    from smoltts_amd.packing import fp8_reference_state
+    from smoltts_amd.prompt import PromptEncoder
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+    from smoltts_amd.tokenizer import load_tokenizer
+
+    cfg = named_config(cfgname)
+    state = synthetic_lm_state(cfg, seed=21)
+    tok = load_tokenizer()
+    eng = LMEngine(cfg, state, TokenConfig.from_tokenizer(tok, cfg), NumericsMode.torch_reference(), weight_format="fp8")
+    assert eng.weight_format == "fp8"
+    rcfg, rstate = fp8_reference_state(cfg, state)
+    orc = LMOracle(OracleLMConfig.from_dict(rcfg.__dict__), rstate)
+    pe = PromptEncoder(tok, 320, cfg.num_codebooks, cfg.duplicate_code_0)
+    rng = np.random.default_rng(5)
+    prompts = [pe.build_prompt("".join(chr(int(c)) for c in rng.integers(32, 127, size=int(rng.integers(3, 50)))), "heart") for _ in range(B)]
+    sess = LMSession(eng, max_batch=B, max_seq=128, max_rows=sum(p.shape[1] for p in prompts), max_frames=frames)
+    sess.prefill(prompts, stop_on_eos=False)
+    sess.decode(frames - 1)
+    codes, n, done, margin = sess.fetch()
+    logs = orc.generate([torch.from_numpy(p) for p in prompts], max_frames=frames, stop_on_eos=False)
+    same = sum(int(np.array_equal(codes[b, :frames].T, logs[b].as_tensor().numpy())) for b in range(B))
+    print(f"{cfgname}: {same}/{B} utterances bit-identical to the oracle on the dequantised model; min margin {margin.min():.2e} / {min(l.min_margin for l in logs):.2e}")
+    assert same >= B - 1
+    # and it is a different model from the bf16 one (the quantisation is really in effect)
+    orc_bf16 = LMOracle(OracleLMConfig.from_dict(cfg.__dict__), state)
+    other = orc_bf16.generate([torch.from_numpy(prompts[0])], max_frames=frames, stop_on_eos=False)[0].as_tensor().numpy()
+    assert not np.array_equal(other, codes[0, :frames].T)
+    sess.close(); eng.close()
