@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--mimi-cus", type=int, default=0, help="with --overlap-mimi: restrict the Mimi stream to this many CUs (hipExtStreamCreateWithCUMask)")
     ap.add_argument("--cu-pattern", default="low", choices=["low", "xcd"], help="which mask bits: the N lowest, or N/32 whole XCDs (bit i -> XCD i mod 8)")
     ap.add_argument("--lm-complement", action="store_true", help="restrict the frame-graph stream to the CUs the Mimi stream does not use")
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"], help="weight format of the DualAR Linears (fp8 = e4m3 + row scales, BASELINE config 5; the model is then the dequantised one)")
     ap.add_argument("--streams", type=int, default=1, help="independent decode streams per GPU (slots are split evenly)")
     args = ap.parse_args()
 
@@ -117,7 +118,7 @@ def main():
     if rank == 0:
         log(f"building synthetic {args.model} + Mimi weights ({torch.get_num_threads()} host threads)")
         state = synthetic_lm_state(cfg, seed=0)
-        arena, offsets = pack_lm(cfg, state, numerics)
+        arena, offsets = pack_lm(cfg, state, numerics, args.weights)
         mstate = synthetic_mimi_state(seed=0)
         m_arena, m_offsets = pack_mimi(mstate, 8, max_positions=2 * total_frames + 16)
         log(f"packed: LM arena {arena.numel() / 1e6:.1f} MB, Mimi arena {m_arena.numel() / 1e6:.1f} MB")
@@ -260,11 +261,12 @@ def main():
         avg_us = (dup - base) / (8 * n_per_frame)
         log(f"in-situ w1|w3 GEMM: frame graph {base / 8:.1f} us -> {dup / 8:.1f} us with {n_per_frame} duplicated launches: {avg_us:.2f} us/launch")
         # algorithmic bytes of one launch: bf16 w1|w3 tiles + X3 operand in (6 B/elem) + X3 h out + partial sums of squares
-        bytes_alg = 2 * cfg.intermediate_size * cfg.dim * 2 + Bs * cfg.dim * 6 + Bs * cfg.intermediate_size * 6 + Bs * (cfg.dim // 16) * 4
+        wbytes = 1 if args.weights == "fp8" else 2
+        bytes_alg = 2 * cfg.intermediate_size * (cfg.dim * wbytes + (4 if args.weights == "fp8" else 0)) + Bs * cfg.dim * 6 + Bs * cfg.intermediate_size * 6 + Bs * (cfg.dim // 16) * 4
         ach = bytes_alg / (avg_us * 1e-6) / 1e9
         traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
         pmc = ROOT / "profiles" / "r01_pmc_w13.json"
-        if pmc.exists() and args.model == "smoltts_byte_150m" and Bs == 32:
+        if pmc.exists() and args.model == "smoltts_byte_150m" and Bs == 32 and args.weights == "bf16":
             traffic = json.loads(pmc.read_text())["hbm_bytes_per_launch"]
         roofline = {"bound": "hbm", "kernel": "gemm3_kernel<MT=1,T=3,U=3,SwiGLU> (RMSNorm-scaled w1|w3 GEMM + SwiGLU)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
@@ -280,7 +282,12 @@ def main():
 
         nF = args.cpu_frames
         log(f"CPU oracle sample: prefill {B} prompts + {nF + 1} frames on {torch.get_num_threads()} threads")
-        orc = LMOracle(OracleLMConfig.from_dict(cfg.__dict__), state, embed_mask=numerics.embed_mask, rope_bf16=numerics.rope_bf16)
+        ocfg, ostate = (cfg, state)
+        if args.weights == "fp8":  # the engine computes the dequantised model: that is what the oracle gets
+            from smoltts_amd.packing import fp8_reference_state
+
+            ocfg, ostate = fp8_reference_state(cfg, state)
+        orc = LMOracle(OracleLMConfig.from_dict(ocfg.__dict__), ostate, embed_mask=numerics.embed_mask, rope_bf16=numerics.rope_bf16)
         with torch.no_grad():
             orc._alloc(B, max_T + nF + 2)
             hidden = torch.stack([orc.prefill_one(b, torch.from_numpy(mine[b]).long()) for b in range(B)])
@@ -349,7 +356,7 @@ def main():
             "metric": "Mimi frames/sec (=12.5 x RTF), greedy DualAR decode + Mimi decode to PCM" + (" [DIAGNOSTIC: Mimi skipped]" if args.no_mimi else ""),
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16 weights, fp32 activations/accumulate (LM); fp32 (Mimi)",
+            "vs_baseline": None, "dtype": f"{'fp8-e4m3 (row-scaled)' if args.weights == 'fp8' else 'bf16'} weights, fp32 activations/accumulate (LM); fp32 (Mimi)",
             "data": "synthetic (seeded random weights at the real shapes, synthetic ChatML prompts)",
             "config": {"workload": f"{args.model} B={B}/GPU concurrent utterances, chunk {CH} frames/step, "
                                    f"prompts T={min(p.shape[1] for p in mine)}..{max_T}, context {max_T + W * CH}..{max_T + (W + K) * CH}",

@@ -286,10 +286,32 @@ int smoltts_mimi_reset(SmolttsMimiSession* s, void* stream) {
   return SMOLTTS_OK;
 }
 
+static int decode_chunk_impl(SmolttsMimiSession* s, const int32_t* codes_dev, int64_t codes_stride, int32_t frame_stride,
+                             int32_t code_offset, int32_t batch, int32_t n_frames, float* pcm_dev, int64_t pcm_stride,
+                             void* stream);
+
 int smoltts_mimi_decode_chunk(SmolttsMimiSession* s, const int32_t* codes_dev, int64_t codes_stride, int32_t frame_stride,
                               int32_t code_offset, int32_t batch, int32_t n_frames, float* pcm_dev, int64_t pcm_stride,
                               void* stream) {
   ST_REQUIRE(s && codes_dev && pcm_dev, SMOLTTS_E_INVALID, "mimi_decode_chunk: null argument");
+  ST_REQUIRE(batch > 0 && n_frames > 0, SMOLTTS_E_INVALID, "mimi_decode_chunk: empty batch or chunk");
+  // the last convolutions run batch * frames * 1920 rows in one launch (<= 65535 * 64): longer chunks are
+  // decoded in pieces, which the streaming state makes equivalent
+  const long per_frame = (long)batch * SAMPLES;
+  const int piece = (int)(4000000L / per_frame) > 0 ? (int)(4000000L / per_frame) : 1;
+  for (int f0 = 0; f0 < n_frames; f0 += piece) {
+    const int n = n_frames - f0 < piece ? n_frames - f0 : piece;
+    ST_TRY(decode_chunk_impl(s, codes_dev + (int64_t)f0 * frame_stride, codes_stride, frame_stride, code_offset, batch, n,
+                             pcm_dev + (int64_t)f0 * SAMPLES, pcm_stride, stream));
+  }
+  return SMOLTTS_OK;
+}
+
+}  // extern "C"
+
+static int decode_chunk_impl(SmolttsMimiSession* s, const int32_t* codes_dev, int64_t codes_stride, int32_t frame_stride,
+                             int32_t code_offset, int32_t batch, int32_t n_frames, float* pcm_dev, int64_t pcm_stride,
+                             void* stream) {
   ST_REQUIRE(batch > 0 && batch <= s->B && n_frames > 0 && n_frames <= s->chunk, SMOLTTS_E_CAPACITY,
              "mimi_decode_chunk: batch=%d frames=%d exceed the session (%d, %d)", batch, n_frames, s->B, s->chunk);
   const SmolttsMimi* m = s->m;
@@ -368,5 +390,3 @@ int smoltts_mimi_decode_chunk(SmolttsMimiSession* s, const int32_t* codes_dev, i
   s->parity ^= 1;
   return SMOLTTS_OK;
 }
-
-}  // extern "C"

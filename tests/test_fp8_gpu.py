@@ -60,7 +60,7 @@ def test_fp8_codes_are_ocp_e4m3(E, ops):
     assert torch.equal(got[:, 0], w2[0])
 
 
-@pytest.mark.parametrize("M", [7, 32, 100, 300])
+@pytest.mark.parametrize("M", [7, 32, 48, 64, 100, 300])
 def test_fp8_gemm_epilogues(E, ops, M):
     from smoltts_amd.packing import rope_table
 
