@@ -135,6 +135,15 @@ int smoltts_lm_prefill(SmolttsSession* s, const int32_t* grid_dev, const int32_t
                        const int32_t* last_row_host, int32_t n_slots, int32_t stop_on_eos,
                        void* stream);
 
+/* Chunked prompt prefill (BASELINE config 5): run the slow transformer over n_rows further prompt rows of
+ * idle slots, filling their KV rows only — no frame is emitted and the listed slots stay idle, so decode
+ * calls for the other slots may run between chunks.  Rows attend to their slot's earlier positions:
+ * chunks of a slot must arrive in position order, and its last chunk goes through smoltts_lm_prefill
+ * (row_pos continuing where the chunks stopped), which emits frame 0.  Arguments as smoltts_lm_prefill. */
+int smoltts_lm_prefill_chunk(SmolttsSession* s, const int32_t* grid_dev, const int32_t* row_slot_dev,
+                             const int32_t* row_pos_dev, int32_t n_rows, const int32_t* slots_host,
+                             const int32_t* last_row_host, int32_t n_slots, void* stream);
+
 /* Decode n_frames further frames for every slot of the session: each frame feeds the previous
  * column back (slow step at the slot's next position), then slow head + n_fast depth steps, all
  * greedy and on device; the frame loop is a captured hipGraph replayed n_frames times.  Slots that

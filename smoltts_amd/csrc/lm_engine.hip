@@ -140,6 +140,17 @@ __global__ void slot_reset_kernel(int B, int n_slots, const int* slots, const in
   }
 }
 
+// Chunked prefill: the listed slots stay idle (done, masked) and their position counter is parked just
+// behind the chunk, where the idle slot's decode rows may scribble without harm (the next chunk rewrites
+// that cache row before any attention reads it).
+__global__ void slot_park_kernel(int B, int n_slots, const int* slots, const int* last_row, const int* row_pos, int* pos,
+                                 int* done, int* mask) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  for (int i = 0; i < n_slots; ++i)
+    if (slots[i] == b) { pos[b] = row_pos[last_row[i]] + 1; done[b] = 1; mask[b] = 0; }
+}
+
 __global__ void decode_mask_kernel(int B, const int* done, int* mask) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) mask[b] = !done[b];
@@ -481,6 +492,28 @@ int smoltts_lm_prefill(SmolttsSession* s, const int32_t* grid_dev, const int32_t
   ST_TRY(run_tail(s, /*advance_pos=*/0, st));
   s->prefilled = true;
   return SMOLTTS_OK;
+}
+
+int smoltts_lm_prefill_chunk(SmolttsSession* s, const int32_t* grid_dev, const int32_t* row_slot_dev, const int32_t* row_pos_dev,
+                             int32_t n_rows, const int32_t* slots_host, const int32_t* last_row_host, int32_t n_slots, void* stream) {
+  ST_REQUIRE(s && grid_dev && row_slot_dev && row_pos_dev && slots_host && last_row_host, SMOLTTS_E_INVALID,
+             "lm_prefill_chunk: null argument");
+  ST_REQUIRE(n_rows > 0 && n_rows <= s->max_rows, SMOLTTS_E_CAPACITY, "lm_prefill_chunk: %d rows, session holds %d", n_rows, s->max_rows);
+  ST_REQUIRE(n_slots > 0 && n_slots <= s->B, SMOLTTS_E_CAPACITY, "lm_prefill_chunk: %d slots, session holds %d", n_slots, s->B);
+  for (int i = 0; i < n_slots; ++i) {
+    ST_REQUIRE(slots_host[i] >= 0 && slots_host[i] < s->B, SMOLTTS_E_INVALID, "lm_prefill_chunk: slot %d out of range", slots_host[i]);
+    ST_REQUIRE(last_row_host[i] >= 0 && last_row_host[i] < n_rows, SMOLTTS_E_INVALID, "lm_prefill_chunk: last_row %d out of range", last_row_host[i]);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  ST_CHECK_HIP(hipStreamSynchronize(st));  // the staging buffer may still be read by an earlier async copy
+  for (int i = 0; i < n_slots; ++i) { s->h_stage[i] = slots_host[i]; s->h_stage[s->B + i] = last_row_host[i]; }
+  ST_CHECK_HIP(hipMemcpyAsync(s->stage_slots, s->h_stage, sizeof(int) * n_slots, hipMemcpyHostToDevice, st));
+  ST_CHECK_HIP(hipMemcpyAsync(s->stage_last, s->h_stage + s->B, sizeof(int) * n_slots, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(slot_park_kernel, dim3((s->B + 63) / 64), dim3(64), 0, st, s->B, n_slots, s->stage_slots, s->stage_last, row_pos_dev,
+                     s->pos, s->done, s->mask);
+  ST_CHECK_HIP(hipGetLastError());
+  ST_TRY(embed_rows(s, grid_dev, n_rows, s->xr, st));
+  return run_slow_layers(s, s->xr, s->qr, n_rows, row_pos_dev, row_slot_dev, /*publish_hidden=*/false, st);
 }
 
 int smoltts_lm_decode(SmolttsSession* s, int32_t n_frames, void* stream) {

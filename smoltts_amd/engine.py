@@ -98,7 +98,7 @@ _EXPORTS = [
     "smoltts_mimi_decode_chunk", "smoltts_k_gemm", "smoltts_k_attention", "smoltts_k_embed", "smoltts_k_argmax",
     "smoltts_k_layernorm", "smoltts_profile_begin", "smoltts_profile_end", "smoltts_k_gemm3", "smoltts_k_x3_pack",
     "smoltts_debug_duplicate", "smoltts_session_drop_graph", "smoltts_session_set_sampling", "smoltts_k_sample",
-    "smoltts_mimi_encoder_create", "smoltts_mimi_encoder_destroy", "smoltts_mimi_encode_frames",
+    "smoltts_lm_prefill_chunk", "smoltts_mimi_encoder_create", "smoltts_mimi_encoder_destroy", "smoltts_mimi_encode_frames",
     "smoltts_mimi_encode_workspace_bytes", "smoltts_mimi_encode",
 ]
 
@@ -150,6 +150,8 @@ def load_library(path: Optional[Path] = None):
                                      C.c_int32, C.c_void_p, C.c_void_p]
     lib.smoltts_debug_duplicate.argtypes = [C.c_int32, C.c_int32]
     lib.smoltts_session_drop_graph.argtypes = [C.c_void_p]
+    lib.smoltts_lm_prefill_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                             C.c_void_p]
     lib.smoltts_mimi_encoder_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.smoltts_mimi_encoder_destroy.argtypes = [C.c_void_p]
     lib.smoltts_mimi_encoder_destroy.restype = None
@@ -305,26 +307,31 @@ class LMSession:
         self.margin = view(ptrs[3], self.B * 4, torch.float32, (self.B,))
         self._keep = None
 
-    def prefill(self, prompts: Sequence[np.ndarray], slots: Optional[Sequence[int]] = None, stop_on_eos: bool = True) -> None:
-        """prompts: one ``(1 + n_fast, T_b)`` int grid per utterance; emits frame 0 of each slot."""
+    def prefill(self, prompts: Sequence[np.ndarray], slots: Optional[Sequence[int]] = None, stop_on_eos: bool = True,
+                pos0: Optional[Sequence[int]] = None, final: bool = True) -> None:
+        """prompts: one ``(1 + n_fast, T_b)`` int grid per utterance; emits frame 0 of each slot.
+
+        Chunked prefill: ``pos0[b]`` is the position of the first column of ``prompts[b]`` (its earlier columns
+        went through previous calls with ``final=False``, which fill the KV cache only and leave the slot idle)."""
         slots = list(range(len(prompts))) if slots is None else list(slots)
         if len(slots) != len(prompts) or len(set(slots)) != len(slots):
             raise ValueError("slots must be distinct and match prompts")
+        pos0 = [0] * len(prompts) if pos0 is None else list(pos0)
         cfg = self.engine.cfg
         cols, rslot, rpos, last = [], [], [], []
         n = 0
-        for g, sl in zip(prompts, slots):
+        for g, sl, p0 in zip(prompts, slots, pos0):
             g = np.asarray(g)
             if g.ndim != 2 or g.shape[0] != self.H or g.shape[1] < 1:
                 raise ValueError(f"prompt grid must be ({self.H}, T>=1), got {g.shape}")
             T = g.shape[1]
-            if T + 1 > self.max_seq:
-                raise SmolttsError(f"prompt of {T} tokens does not fit max_seq={self.max_seq}")
+            if p0 + T + 1 > self.max_seq:
+                raise SmolttsError(f"prompt of {p0 + T} tokens does not fit max_seq={self.max_seq}")
             if g[0].min() < 0 or g[0].max() >= cfg.vocab_size or g[1:].min() < 0 or g[1:].max() >= cfg.codebook_size:
                 raise ValueError("prompt ids out of range")
             cols.append(np.ascontiguousarray(g.T.astype(np.int32)))
             rslot.append(np.full(T, sl, np.int32))
-            rpos.append(np.arange(T, dtype=np.int32))
+            rpos.append(np.arange(p0, p0 + T, dtype=np.int32))
             n += T
             last.append(n - 1)
         if n > self.max_rows:
@@ -336,8 +343,31 @@ class LMSession:
         slots_h = (C.c_int32 * len(slots))(*slots)
         last_h = (C.c_int32 * len(slots))(*last)
         self._keep = (grid_d, rslot_d, rpos_d)  # alive until the stream has consumed them
-        check(self.lib.smoltts_lm_prefill(self.handle, dptr(grid_d), dptr(rslot_d), dptr(rpos_d), n, slots_h, last_h,
-                                          len(slots), int(stop_on_eos), current_stream_ptr()), "smoltts_lm_prefill")
+        if final:
+            check(self.lib.smoltts_lm_prefill(self.handle, dptr(grid_d), dptr(rslot_d), dptr(rpos_d), n, slots_h, last_h,
+                                              len(slots), int(stop_on_eos), current_stream_ptr()), "smoltts_lm_prefill")
+        else:
+            check(self.lib.smoltts_lm_prefill_chunk(self.handle, dptr(grid_d), dptr(rslot_d), dptr(rpos_d), n, slots_h, last_h,
+                                                    len(slots), current_stream_ptr()), "smoltts_lm_prefill_chunk")
+
+    def prefill_chunked(self, prompts: Sequence[np.ndarray], slots: Optional[Sequence[int]] = None, stop_on_eos: bool = True,
+                        chunk: int = 128, between=None) -> None:
+        """The same result as ``prefill`` with at most ``chunk`` columns per utterance per call; ``between()`` runs
+        after every partial call (e.g. a few decode frames for the slots that are already speaking)."""
+        slots = list(range(len(prompts))) if slots is None else list(slots)
+        prompts = [np.asarray(g) for g in prompts]
+        done = [0] * len(prompts)
+        while True:
+            part = [i for i, g in enumerate(prompts) if g.shape[1] - done[i] > chunk]
+            if not part:
+                break
+            self.prefill([prompts[i][:, done[i]: done[i] + chunk] for i in part], [slots[i] for i in part], stop_on_eos,
+                         pos0=[done[i] for i in part], final=False)
+            for i in part:
+                done[i] += chunk
+            if between is not None:
+                between()
+        self.prefill([g[:, d:] for g, d in zip(prompts, done)], slots, stop_on_eos, pos0=done, final=True)
 
     def set_sampling(self, temp: float = 0.0, fast_temp: float = 0.0, min_p: float = 0.0, seed: int = 0) -> None:
         """temp / fast_temp <= 0: greedy (default). Takes effect from the next frame."""

@@ -4,7 +4,8 @@ The reference serves one request at a time (its handlers call the model inline,
 mlx_inference/.../server/routes/openai.py:17-28).  Here one worker thread owns an ``LMSession`` with
 ``max_batch`` slots: new requests are prefilled into free slots while the other slots keep decoding
 (``smoltts_lm_prefill`` restarts only the listed slots), every tick decodes a few frames for all slots,
-finished slots (``<|im_end|>`` or frame budget) are released.  Audio is produced per request by its
+finished slots (``<|im_end|>`` or frame budget) are released.  Prompts longer than ``prefill_chunk`` columns are
+prefilled in chunks (``smoltts_lm_prefill_chunk``) with a decode tick for the speaking slots between chunks.  Audio is produced per request by its
 own streaming Mimi session, so blocking and streaming responses share one code path and a request's
 PCM is identical to what ``SmolTTS.__call__`` / ``stream`` return for it alone.
 """
@@ -32,7 +33,8 @@ class _Request:
 
 
 class BatchScheduler:
-    def __init__(self, tts, max_batch: int = 32, frames_per_tick: int = 4, generation_settings=None, max_prompt_rows: int = 4096):
+    def __init__(self, tts, max_batch: int = 32, frames_per_tick: int = 4, generation_settings=None, max_prompt_rows: int = 4096,
+                 prefill_chunk: Optional[int] = 128):
         import torch
 
         from ..config import GenerationSettings
@@ -42,6 +44,7 @@ class BatchScheduler:
         self.tts = tts
         self.B = max_batch
         self.tick = frames_per_tick
+        self.prefill_chunk = prefill_chunk  # columns per utterance per prefill call (None: whole prompts at once)
         self.settings = generation_settings or GenerationSettings.greedy()
         self.max_frames = self.settings.max_new_tokens + 1
         self.session = LMSession(tts.lm, max_batch, max_seq=tts.config.max_seq_len, max_rows=max(max_prompt_rows, max_batch),
@@ -98,7 +101,17 @@ class BatchScheduler:
             return
         from ..engine import MimiSession
 
-        self.session.prefill([r.prompt for r in new], slots=[r.slot for r in new], stop_on_eos=True)
+        if self.prefill_chunk:
+            # long prompts (voice-clone speakers) enter in chunks; the slots already speaking get a tick in between
+            def between():
+                if self._active:
+                    self.session.decode(self.tick)
+                    self._drain()
+
+            self.session.prefill_chunked([r.prompt for r in new], slots=[r.slot for r in new], stop_on_eos=True,
+                                         chunk=self.prefill_chunk, between=between)
+        else:
+            self.session.prefill([r.prompt for r in new], slots=[r.slot for r in new], stop_on_eos=True)
         self._started = True
         for r in new:
             r.msess = MimiSession(self.tts.codec, max_batch=1, max_chunk_frames=max(self.tick, 1) + 1)

@@ -23,7 +23,9 @@ def test_scheduler_matches_single_request_results():
     for text, voice, n, stream in reqs:
         gs = GenerationSettings.greedy(max_new_tokens=n)
         want.append(np.concatenate(list(tts.stream(text, voice, generation_settings=gs))) if stream else tts(text, voice, generation_settings=gs))
-    sched = BatchScheduler(tts, max_batch=3, frames_per_tick=2, generation_settings=GenerationSettings.greedy(max_new_tokens=16))
+    # prefill_chunk=8: every prompt enters in several chunks, with decode ticks of the speaking slots in between
+    sched = BatchScheduler(tts, max_batch=3, frames_per_tick=2, generation_settings=GenerationSettings.greedy(max_new_tokens=16),
+                           prefill_chunk=8)
     got = [None] * len(reqs)
 
     def worker(i):
