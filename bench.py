@@ -268,7 +268,7 @@ def main():
         pmc = ROOT / "profiles" / "r01_pmc_w13.json"
         if pmc.exists() and args.model == "smoltts_byte_150m" and Bs == 32 and args.weights == "bf16":
             traffic = json.loads(pmc.read_text())["hbm_bytes_per_launch"]
-        roofline = {"bound": "hbm", "kernel": "gemm3_kernel<MT=1,T=3,U=3,SwiGLU> (RMSNorm-scaled w1|w3 GEMM + SwiGLU)",
+        roofline = {"bound": "hbm", "kernel": "gemm3_kernel<1, 3, 3, 2, false> = MT 1, T 3, U 3, SwiGLU epilogue, bf16 weights (RMSNorm-scaled w1|w3 GEMM)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "avg_us": round(avg_us, 3), "launches_timed": 8 * n_per_frame * 3,
                     "bytes_per_launch": bytes_alg, "method": "graph replay with duplicated launches, HIP events"}
