@@ -352,6 +352,10 @@ typedef struct SmolttsGemm3Args {
   int32_t n_q_heads, n_kv_heads, cache_len;
   int32_t w_format;            /* SMOLTTS_W_BF16 | SMOLTTS_W_FP8 */
   const float* w_scale_dev;    /* SMOLTTS_W_FP8: [N] row scales; NULL otherwise */
+  void* v_x3_dev;              /* EPI_QKV_ROPE, optional: every row sits at position 0, so its attention output is its own
+                                  V row (softmax over one key): V is also written as the X3 operand [M][n_q_heads*64] of
+                                  the output projection (each kv head repeated for its query heads) and no attention
+                                  launch is needed */
 } SmolttsGemm3Args;
 
 int smoltts_k_gemm3(const SmolttsGemm3Args* a, void* stream);

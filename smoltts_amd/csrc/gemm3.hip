@@ -45,6 +45,7 @@ struct Gemm3Dev {
   const int* row_slot;
   float* kc;
   float* vc;
+  char* v_x3;  // QKV_ROPE, rows at position 0: attention over one key is V itself -> V published as wo's X3 operand
   int n_q_heads, n_kv_heads, cache_len;
   unsigned long long* stamps;  // diagnostics only (smoltts_debug_set_stamps); nullptr in production
 };
@@ -304,6 +305,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
           float* base = nn < kd ? p.kc : p.vc;
           const int h = (nn < kd ? nn : nn - kd) >> 6, d = nn & 63;
           *reinterpret_cast<float4*>(base + (((long)slot * p.n_kv_heads + h) * p.cache_len + pos) * 64 + d) = o;
+          if (p.v_x3 != nullptr && nn >= kd) {
+            const int G = p.n_q_heads / p.n_kv_heads;
+            for (int g = 0; g < G; ++g) x3_emit4(p.v_x3, m, (h * G + g) * 64 + d, (p.n_q_heads * 64) >> 5, v[0], v[1], v[2], v[3]);
+          }
         }
       }
     }
@@ -444,6 +449,10 @@ __global__ __launch_bounds__(256) void gemm3_rows_kernel(Gemm3Dev p) {
             float* base = nn < kd ? p.kc : p.vc;
             const int h = (nn < kd ? nn : nn - kd) >> 6, d = nn & 63;
             *reinterpret_cast<float4*>(base + (((long)slot * p.n_kv_heads + h) * p.cache_len + pos) * 64 + d) = o;
+            if (p.v_x3 != nullptr && nn >= kd) {
+              const int G = p.n_q_heads / p.n_kv_heads;
+              for (int g = 0; g < G; ++g) x3_emit4(p.v_x3, m, (h * G + g) * 64 + d, (p.n_q_heads * 64) >> 5, v[0], v[1], v[2], v[3]);
+            }
           }
         }
       }
@@ -546,6 +555,7 @@ static int launch_gemm3_impl(const SmolttsGemm3Args& a, hipStream_t stream) {
   d.emit.gamma_b = a.gamma_b_dev; d.emit.ssq = a.ssq_out_dev;
   d.rope = a.rope_dev; d.row_pos = a.row_pos_dev; d.row_slot = a.row_slot_dev; d.kc = a.k_cache_dev; d.vc = a.v_cache_dev;
   d.n_q_heads = a.n_q_heads; d.n_kv_heads = a.n_kv_heads; d.cache_len = a.cache_len;
+  d.v_x3 = a.epilogue == SMOLTTS_EPI_QKV_ROPE ? (char*)a.v_x3_dev : nullptr;
   d.stamps = debug_stamp_buffer();
   switch (a.epilogue) {
     case SMOLTTS_EPI_STORE:

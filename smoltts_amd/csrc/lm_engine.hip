@@ -189,7 +189,9 @@ SmolttsGemm3Args base3(int fmt, const void* w, const void* x3, int M, int N, int
 // `in_x3`/ssq: x published for the wqkv GEMM by whoever produced x; `next`: where the block publishes its output.
 int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, int n_head, int n_kv, int inter, float* x,
               float* q, int M, const int* row_pos, const int* row_slot, const float* rope, float* kc, float* vc,
-              int cache_len, const char* in_x3, const EmitArgs& next, hipStream_t st) {
+              int cache_len, const char* in_x3, const EmitArgs& next, hipStream_t st, bool first_pos = false) {
+  // first_pos: every row is at position 0 (depth step 0), so attention over its single key is the row's own V: the QKV
+  // epilogue publishes V as wo's operand and the attention launch is skipped.
   const SmolttsEngine* e = s->e;
   const char* A = e->arena;
   const float eps = e->cfg.norm_eps;
@@ -198,9 +200,10 @@ int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, i
     a.ssq_in_dev = s->ssq; a.eps = eps; a.out_dev = q; a.ldo = n_head * 64;
     a.rope_dev = rope; a.row_pos_dev = row_pos; a.row_slot_dev = row_slot;
     a.k_cache_dev = kc; a.v_cache_dev = vc; a.n_q_heads = n_head; a.n_kv_heads = n_kv; a.cache_len = cache_len;
+    if (first_pos) a.v_x3_dev = s->x3a;
     ST_TRY(launch_gemm3(a, st));
   }
-  ST_TRY(launch_attention(q, kc, vc, row_pos, row_slot, M, n_head, n_kv, cache_len, 0, nullptr, s->x3a, st));
+  if (!first_pos) ST_TRY(launch_attention(q, kc, vc, row_pos, row_slot, M, n_head, n_kv, cache_len, 0, nullptr, s->x3a, st));
   {  // x += attn . Wo^T ; publish x * ffn_norm for w1|w3
     SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.wo, s->x3a, M, dim, dim, SMOLTTS_EPI_RESID);
     a.resid_dev = x; a.out_dev = x; a.ldo = dim;
@@ -276,7 +279,7 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
                           nullptr, nullptr, s->ssq};
       ST_TRY(run_block(s, e->w.fast_layers[l], c.fast_dim, c.fast_n_head, c.fast_n_kv_head, c.fast_inter, xf, s->qt, B,
                        s->fastpos + (size_t)i * B, s->iota, (const float*)(A + e->w.fast_rope), s->fkc + l * fl_stride,
-                       s->fvc + l * fl_stride, c.n_fast, (i == 0 && l == 0) ? first_x3 : s->x3n, next, st));
+                       s->fvc + l * fl_stride, c.n_fast, (i == 0 && l == 0) ? first_x3 : s->x3n, next, st, /*first_pos=*/i == 0));
     }
     {  // fast_norm + depthwise head slice i  (lm/rq_transformer.py:209-217)
       const size_t wrow = (size_t)i * e->w.fast_head_step_stride;  // rows; a row tile is 16 rows

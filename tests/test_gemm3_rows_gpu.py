@@ -98,3 +98,27 @@ def test_rows_swiglu_and_qkv(E, ops):
     kcc, vcc = kc.cpu(), vc.cpu()
     assert rel_err(kcc[row_slot.long(), :, row_pos.long()], kref) < 3e-5
     assert rel_err(vcc[row_slot.long(), :, row_pos.long()], v.view(M, Hkv, 64)) < 3e-5
+
+
+@pytest.mark.parametrize("M", [20, 300])
+def test_position_zero_publishes_v_as_attention_output(E, ops, M):
+    """v_x3: rows at position 0 attend to one key, so the attention output is V (repeated per query head)."""
+    from smoltts_amd.packing import rope_table
+
+    g = torch.Generator().manual_seed(M)
+    K, Hq, Hkv = 384, 6, 2
+    N = (Hq + 2 * Hkv) * 64
+    x = torch.randn(M, K, generator=g)
+    w = bf16r(torch.randn(N, K, generator=g) * 0.05)
+    x3, _, _ = ops.x3_pack(x.cuda())
+    rope = rope_table(8, 64, 100000.0, bf16=True)
+    pos = torch.zeros(M, dtype=torch.int32)
+    slot = torch.arange(M, dtype=torch.int32)
+    kc, vc = torch.zeros(M, Hkv, 8, 64).cuda(), torch.zeros(M, Hkv, 8, 64).cuda()
+    vx3 = ops.x3_alloc(M, Hq * 64)
+    q = ops.linear3(x3, ops.pack_weight(w), M, N, K, epilogue=E.EPI_QKV_ROPE, rope=rope.cuda(), row_pos=pos.cuda(), row_slot=slot.cuda(),
+                    k_cache=kc, v_cache=vc, n_q_heads=Hq, n_kv_heads=Hkv, cache_len=8, v_x3=vx3)
+    want = ops.attention(q, kc, vc, pos.cuda(), slot.cuda(), Hq)  # the real attention kernel over the one-entry cache
+    got = ops.x3_to_float(vx3, M, Hq * 64)
+    assert torch.equal(got, want.cpu())
+    assert torch.equal(got.view(M, Hkv, Hq // Hkv, 64)[:, :, 0], vc.cpu()[:, :, 0])
