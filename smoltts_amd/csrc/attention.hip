@@ -236,9 +236,25 @@ __global__ __launch_bounds__(256) void attn_short_kernel(AttnDev p, int n_pairs)
   }
 }
 
+int debug_dup_code();  // gemm3.hip (smoltts_debug_duplicate): 100 = duplicate short-cache attention, 101 = long-cache
+
+static int launch_attention_once(const float* q, const float* kc, const float* vc, const int32_t* row_pos, const int32_t* row_slot,
+                                 int n_rows, int n_q_heads, int n_kv_heads, int cache_len, int window, float* out, void* out_x3,
+                                 hipStream_t stream);
+
 int launch_attention(const float* q, const float* kc, const float* vc, const int32_t* row_pos, const int32_t* row_slot,
                      int n_rows, int n_q_heads, int n_kv_heads, int cache_len, int window, float* out, void* out_x3,
                      hipStream_t stream) {
+  const int dup = debug_dup_code();  // measurement aid (tools/marginal_cost.py): the launch is idempotent
+  const int reps = (dup == 100 && cache_len <= 16) || (dup == 101 && cache_len > 16) ? 2 : 1;
+  for (int i = 0; i < reps; ++i)
+    ST_TRY(launch_attention_once(q, kc, vc, row_pos, row_slot, n_rows, n_q_heads, n_kv_heads, cache_len, window, out, out_x3, stream));
+  return SMOLTTS_OK;
+}
+
+static int launch_attention_once(const float* q, const float* kc, const float* vc, const int32_t* row_pos, const int32_t* row_slot,
+                                 int n_rows, int n_q_heads, int n_kv_heads, int cache_len, int window, float* out, void* out_x3,
+                                 hipStream_t stream) {
   ST_REQUIRE(q && kc && vc && row_pos && row_slot && (out || out_x3), SMOLTTS_E_INVALID, "attention: null pointer");
   ST_REQUIRE(n_rows > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0 && cache_len > 0, SMOLTTS_E_INVALID,
              "attention: bad shape rows=%d q_heads=%d kv_heads=%d cache_len=%d", n_rows, n_q_heads, n_kv_heads, cache_len);

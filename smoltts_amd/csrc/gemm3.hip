@@ -528,6 +528,7 @@ static int launch_gemm3_impl(const SmolttsGemm3Args& a, hipStream_t stream);
 // second launch recomputes the same outputs, so a frame graph captured with the filter on costs
 // exactly n extra launches of that kernel in situ: (t_dup - t_base) / n is its per-launch time.
 static int g_dup_epi = -1, g_dup_n = 0;
+int debug_dup_code() { return g_dup_epi; }
 
 int launch_gemm3(const SmolttsGemm3Args& a, hipStream_t stream) {
   // the event hook sees a normed input as the RMSNorm prologue
