@@ -87,3 +87,24 @@ def test_capacity_error(mimi):
     with pytest.raises(SmolttsError):
         sess.decode(codes)  # 400 positions > max_positions=256
     sess.close()
+
+
+def test_long_chunks_are_decoded_in_pieces():
+    """batch * frames * 1920 rows beyond one launch's grid: smoltts_mimi_decode_chunk cuts the chunk into pieces, which
+    the streaming state makes equivalent to separate calls."""
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+    from smoltts_amd.engine import MimiEngine, MimiSession
+
+    eng = MimiEngine(synthetic_mimi_state(seed=1), 8, max_positions=700)
+    B, F = 8, 280  # 8 * 280 * 1920 = 4.3 M rows > 4 M
+    g = torch.Generator().manual_seed(0)
+    codes = torch.randint(0, 2048, (B, F, 8), generator=g, dtype=torch.int32).cuda()
+    big = MimiSession(eng, max_batch=B, max_chunk_frames=F)
+    one = big.decode(codes)
+    big.close()
+    small = MimiSession(eng, max_batch=B, max_chunk_frames=70)
+    four = small.decode(codes)  # four calls of 70 frames
+    small.close()
+    assert one.shape == (B, F * 1920) and bool(torch.isfinite(one).all())
+    assert float((one - four).abs().max()) < 1e-5
+    eng.close()
