@@ -281,7 +281,9 @@ __global__ __launch_bounds__(MT >= 4 ? 512 : 1024) void gemm_kernel(GemmDev p) {
 // there is no cross-wave reduction and the epilogue stores straight from the accumulators.
 template <int NTW, int EPI>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmDev p, int WN) {
-  __shared__ __attribute__((aligned(16))) float xs[4 * 4 * 64 * 8];  // [row group][q][row][8]
+  // [row group][row][8 float4], the float4 column xor-swizzled with (row >> 1) & 7: the 16-lane phases of both the
+  // staging writes (2 rows x 8 columns) and the fragment reads (16 rows x 1 column) then hit 16 distinct bank groups
+  __shared__ __attribute__((aligned(16))) float xs[4 * 64 * 8 * 4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, q = lane >> 4;
   const int WM = 4 / WN;
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmDev p, int WN) {
     const int m = row0 + rg * 64 + row;
     const bool v = i < 2 * WM && m < p.M;
     sp[i] = v ? p.x + row_off(m, p.rows_per_batch, p.ldx, p.x_bstride) + kq * 4 : nullptr;
-    sdst[i] = ((rg * 4 + (kq >> 1)) * 64 + row) * 8 + (kq & 1) * 4;
+    sdst[i] = ((rg * 64 + row) * 8 + (kq ^ ((row >> 1) & 7))) * 4;
   }
   const char* wb[NTW];
   bool wv[NTW];
@@ -343,22 +345,38 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmDev p, int WN) {
     }
     __syncthreads();
     if (c + 1 < nchunks) fetch(c + 1);  // next chunk's global loads fly under this chunk's MFMAs
+    float xv[4][8];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      const float* xp = xs + ((wm * 4 + q) * 64 + mt * 16 + r) * 8;
-      const float4 x0 = *reinterpret_cast<const float4*>(xp), x1 = *reinterpret_cast<const float4*>(xp + 4);
-      const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-#pragma unroll
-      for (int t = 0; t < NTW; ++t)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[t][j], xv[j], acc[t][mt], 0, 0, 0);
+      const int row = mt * 16 + r, sw = (row >> 1) & 7;
+      const float* xrow = xs + (wm * 64 + row) * 32;
+      const float4 x0 = *reinterpret_cast<const float4*>(xrow + ((2 * q) ^ sw) * 4);
+      const float4 x1 = *reinterpret_cast<const float4*>(xrow + ((2 * q + 1) ^ sw) * 4);
+      xv[mt][0] = x0.x; xv[mt][1] = x0.y; xv[mt][2] = x0.z; xv[mt][3] = x0.w;
+      xv[mt][4] = x1.x; xv[mt][5] = x1.y; xv[mt][6] = x1.z; xv[mt][7] = x1.w;
     }
+    // consecutive MFMAs go to different accumulators (4 x NTW of them): no wait on the 40-cycle dependent latency
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+#ifndef SMOLTTS_DBG_NO_MFMA
+          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[t][j], xv[mt][j], acc[t][mt], 0, 0, 0);
+#else
+          acc[t][mt][0] += wcur[t][j] * xv[mt][j];  // bottleneck experiment: one scalar fma instead of the MFMA
+#endif
+        }
   }
 
   // ---- epilogue straight from the accumulators: lane holds out[m = rows + mt*16 + r][n0 .. n0+4)
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int m = row0 + wm * 64 + mt * 16 + r;
+#ifdef SMOLTTS_DBG_NO_STORE
+    if (acc[0][mt][0] != 12345.678f) continue;  // bottleneck experiment: (almost) never store
+#endif
     if (m >= p.M) continue;
     const long orow = row_off(m, p.rows_per_batch, p.ldo, p.o_bstride);
 #pragma unroll
@@ -418,17 +436,20 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmDev p, int WN) {
   }
 }
 
+// Column tiles per wave of the many-row kernel.  Two, not four, even for wide outputs: 152 instead of 220 registers
+// keep three workgroups per CU resident, which measured 0-11 % faster on the SEANet shapes (tools/microbench_rows.py).
+static int rows_ntw(int ntiles) { return ntiles >= 8 ? 2 : 1; }
+
 template <int EPI>
 static int launch_rows(const GemmDev& d, hipStream_t stream) {
   const int ntiles = (d.N + 15) / 16;
-  const int NTW = ntiles >= 16 ? 4 : (ntiles >= 8 ? 2 : 1);
+  const int NTW = rows_ntw(ntiles);
   const int per = (ntiles + NTW - 1) / NTW;       // column-tile groups a workgroup could hold
   const int WN = per >= 4 ? 4 : (per >= 2 ? 2 : 1);
   const int WM = 4 / WN;
   const dim3 grid((per + WN - 1) / WN, (d.M + 64 * WM - 1) / (64 * WM));
   ST_REQUIRE(grid.y <= 65535, SMOLTTS_E_INVALID, "gemm: M=%d too large for one launch", d.M);
-  if (NTW == 4) hipLaunchKernelGGL((gemm_rows_kernel<4, EPI>), grid, dim3(256), 0, stream, d, WN);
-  else if (NTW == 2) hipLaunchKernelGGL((gemm_rows_kernel<2, EPI>), grid, dim3(256), 0, stream, d, WN);
+  if (NTW == 2) hipLaunchKernelGGL((gemm_rows_kernel<2, EPI>), grid, dim3(256), 0, stream, d, WN);
   else hipLaunchKernelGGL((gemm_rows_kernel<1, EPI>), grid, dim3(256), 0, stream, d, WN);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
@@ -531,7 +552,7 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
   long rows_grid = 0;
   {
     const int ntiles = (a.N + 15) / 16;
-    const int NTW = ntiles >= 16 ? 4 : (ntiles >= 8 ? 2 : 1);
+    const int NTW = rows_ntw(ntiles);
     const int per = (ntiles + NTW - 1) / NTW;
     const int WN = per >= 4 ? 4 : (per >= 2 ? 2 : 1);
     rows_grid = (long)((per + WN - 1) / WN) * ((a.M + 64 * (4 / WN) - 1) / (64 * (4 / WN)));
