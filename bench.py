@@ -344,7 +344,7 @@ def main():
         a70, o70 = pack_lm(cfg70, synthetic_lm_state(cfg70, seed=0), numerics)
         eng70 = LMEngine(cfg70, None, TokenConfig.from_tokenizer(tok, cfg70), numerics, arena=a70, offsets=o70)
         t70 = []
-        for u in range(40):
+        for u in range(200):  # p50 / p95 over 200 prompts
             t70 += first_chunk_ms(eng70, meng, [all_prompts[u % len(all_prompts)]], 1)
         first_chunk = {"b32_150m_ms_p50": round(float(np.median(t150)), 2),
                        "b1_70m_ms_p50": round(float(np.median(t70)), 2), "b1_70m_ms_p95": round(float(np.percentile(t70, 95)), 2),
