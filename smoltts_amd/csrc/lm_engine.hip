@@ -53,8 +53,10 @@ struct SmolttsSession {
   int* codes;                // [B][max_frames][1+n_fast]
   // host staging (pinned)
   int* h_stage;
-  hipGraphExec_t graph_exec;
+  hipGraphExec_t graph_exec;   // one decode frame (slow step + tail)
   bool graph_ready;
+  hipGraphExec_t tail_exec;    // the tail alone (slow head + depth steps + commit) as run after a prefill
+  bool tail_ready;
   bool prefilled;
 };
 
@@ -339,6 +341,41 @@ int run_decode_frame(SmolttsSession* s, hipStream_t st) {
   return run_tail(s, /*advance_pos=*/1, st);
 }
 
+void drop_graphs(SmolttsSession* s) {
+  if (s->graph_ready) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_ready = false; }
+  if (s->tail_ready) { (void)hipGraphExecDestroy(s->tail_exec); s->tail_ready = false; }
+}
+
+// Record `body` (a fixed launch sequence on the given stream) into an executable graph.
+template <typename F>
+int capture_graph(hipStream_t st, hipGraphExec_t* exec, F body) {
+  hipStream_t cap = st;
+  bool own = false;
+  if (cap == nullptr) {  // the legacy default stream cannot be captured
+    ST_CHECK_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+    own = true;
+  }
+  ST_CHECK_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+  const int rc = body(cap);
+  hipGraph_t graph = nullptr;
+  const hipError_t ee = hipStreamEndCapture(cap, &graph);
+  if (own) (void)hipStreamDestroy(cap);
+  if (rc != SMOLTTS_OK) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+  }
+  ST_CHECK_HIP(ee);
+  const hipError_t ei = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  ST_CHECK_HIP(ei);
+  return SMOLTTS_OK;
+}
+
+bool graphs_enabled() {
+  const char* no_graph = getenv("SMOLTTS_NO_GRAPH");
+  return !(no_graph && no_graph[0] == '1');
+}
+
 int check_offsets(const SmolttsLMConfig& c, const SmolttsLMWeights& w, size_t bytes) {
   auto ok = [&](uint64_t off, size_t need) { return off % 16 == 0 && off + need <= bytes; };
   ST_REQUIRE(c.weight_format == SMOLTTS_W_BF16 || c.weight_format == SMOLTTS_W_FP8, SMOLTTS_E_INVALID,
@@ -452,7 +489,7 @@ int smoltts_session_create(SmolttsEngine* e, void* slab_dev, size_t slab_bytes, 
 
 void smoltts_session_destroy(SmolttsSession* s) {
   if (!s) return;
-  if (s->graph_ready) (void)hipGraphExecDestroy(s->graph_exec);
+  drop_graphs(s);
   if (s->h_stage) (void)hipHostFree(s->h_stage);
   delete s;
 }
@@ -471,10 +508,7 @@ int smoltts_lm_prefill(SmolttsSession* s, const int32_t* grid_dev, const int32_t
   hipStream_t st = (hipStream_t)stream;
   const SmolttsEngine* e = s->e;
   const SmolttsLMConfig& c = e->cfg;
-  if (s->stop_on_eos != stop_on_eos && s->graph_ready) {  // the flag is baked into the captured commit node
-    (void)hipGraphExecDestroy(s->graph_exec);
-    s->graph_ready = false;
-  }
+  if (s->stop_on_eos != stop_on_eos) drop_graphs(s);  // the flag is baked into the captured commit nodes
   s->stop_on_eos = stop_on_eos;
   // the staging buffer may still be read by an earlier async copy on this stream
   ST_CHECK_HIP(hipStreamSynchronize(st));
@@ -492,7 +526,17 @@ int smoltts_lm_prefill(SmolttsSession* s, const int32_t* grid_dev, const int32_t
     const EmitArgs em = slow_hidden_emit(s);
     ST_TRY(launch_x3_pack(s->xt, c.dim, s->B, c.dim, em.x3a, em.gamma_a, em.x3b, em.gamma_b, em.ssq, st));
   }
-  ST_TRY(run_tail(s, /*advance_pos=*/0, st));
+  // frame 0: the tail is the same ~180 launches after every prefill -> replayed from a graph (host launch time is what
+  // a single short prompt waits for)
+  if (graphs_enabled()) {
+    if (!s->tail_ready) {
+      ST_TRY(capture_graph(st, &s->tail_exec, [&](hipStream_t cap) { return run_tail(s, /*advance_pos=*/0, cap); }));
+      s->tail_ready = true;
+    }
+    ST_CHECK_HIP(hipGraphLaunch(s->tail_exec, st));
+  } else {
+    ST_TRY(run_tail(s, /*advance_pos=*/0, st));
+  }
   s->prefilled = true;
   return SMOLTTS_OK;
 }
@@ -524,31 +568,12 @@ int smoltts_lm_decode(SmolttsSession* s, int32_t n_frames, void* stream) {
   ST_REQUIRE(s->prefilled, SMOLTTS_E_STATE, "lm_decode: call smoltts_lm_prefill first");
   ST_REQUIRE(n_frames >= 0, SMOLTTS_E_INVALID, "lm_decode: n_frames < 0");
   hipStream_t st = (hipStream_t)stream;
-  const char* no_graph = getenv("SMOLTTS_NO_GRAPH");
-  if (no_graph && no_graph[0] == '1') {
+  if (!graphs_enabled()) {
     for (int f = 0; f < n_frames; ++f) ST_TRY(run_decode_frame(s, st));
     return SMOLTTS_OK;
   }
   if (!s->graph_ready) {
-    hipStream_t cap = st;
-    bool own = false;
-    if (cap == nullptr) {  // the legacy default stream cannot be captured
-      ST_CHECK_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
-      own = true;
-    }
-    ST_CHECK_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
-    const int rc = run_decode_frame(s, cap);
-    hipGraph_t graph = nullptr;
-    const hipError_t ee = hipStreamEndCapture(cap, &graph);
-    if (own) (void)hipStreamDestroy(cap);
-    if (rc != SMOLTTS_OK) {
-      if (graph) (void)hipGraphDestroy(graph);
-      return rc;
-    }
-    ST_CHECK_HIP(ee);
-    const hipError_t ei = hipGraphInstantiate(&s->graph_exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    ST_CHECK_HIP(ei);
+    ST_TRY(capture_graph(st, &s->graph_exec, [&](hipStream_t cap) { return run_decode_frame(s, cap); }));
     s->graph_ready = true;
   }
   for (int f = 0; f < n_frames; ++f) ST_CHECK_HIP(hipGraphLaunch(s->graph_exec, st));
@@ -562,20 +587,14 @@ int smoltts_session_set_sampling(SmolttsSession* s, float temp, float fast_temp,
   ST_REQUIRE(s, SMOLTTS_E_INVALID, "session_set_sampling: null session");
   ST_REQUIRE(min_p < 1.0f, SMOLTTS_E_INVALID, "session_set_sampling: min_p must be < 1");
   s->temp = temp; s->fast_temp = fast_temp; s->min_p = min_p; s->seed = seed;
-  if (s->graph_ready) {
-    (void)hipGraphExecDestroy(s->graph_exec);
-    s->graph_ready = false;
-  }
+  drop_graphs(s);
   return SMOLTTS_OK;
 }
 
 // Forget the captured frame graph (the next smoltts_lm_decode captures it again).
 int smoltts_session_drop_graph(SmolttsSession* s) {
   ST_REQUIRE(s, SMOLTTS_E_INVALID, "session_drop_graph: null session");
-  if (s->graph_ready) {
-    (void)hipGraphExecDestroy(s->graph_exec);
-    s->graph_ready = false;
-  }
+  drop_graphs(s);
   return SMOLTTS_OK;
 }
 
