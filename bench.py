@@ -110,6 +110,14 @@ def main():
     tok = load_tokenizer()
     tc = TokenConfig.from_tokenizer(tok, cfg)
     numerics = NumericsMode.torch_reference()
+    # a slot's context may not outgrow the model's RoPE table: longest prompt (T <= 176 for these prompts) + all frames.
+    # Many steps => fewer frames per step (logged; the JSON line names the chunk actually used).
+    ch_max = (cfg.max_seq_len - 176 - 16) // max(W + K, 1)
+    if ch_max < 1:
+        raise SystemExit(f"--steps {K} --warmup {W}: even one frame per step exceeds max_seq_len={cfg.max_seq_len}")
+    if CH > ch_max:
+        log(f"chunk {CH} -> {ch_max} frames per step so that {W + K} steps fit max_seq_len={cfg.max_seq_len}")
+        CH = ch_max
     total_frames = 1 + (W + K) * CH + 4  # frame 0 from prefill, +4 for the in-situ kernel timing frames
 
     # ---- weights: rank 0 builds + packs, everyone receives them over RCCL
