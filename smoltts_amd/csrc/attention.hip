@@ -310,6 +310,170 @@ __global__ __launch_bounds__(256) void attn_rows4_kernel(AttnDev p, int n_rows) 
   }
 }
 
+// Prompt prefill with GQA (many rows, G > 1): flash-style attention on the fp32 matrix cores.  One workgroup per
+// (16 consecutive rows, G query heads); keys in tiles of 16 dealt round-robin to its 4 waves; per tile and query head 16 v_mfma_f32_16x16x4_f32 for
+// S = K Q^T and 16 for O += V^T P, every K / V tile loaded once for 16 rows x G heads (exact fp32 products, fp32
+// accumulation: the same arithmetic class as the per-row kernel).  Fragment bookkeeping, lane l = 16 q + r:
+//   S:  A = K  (lane supplies K[key r][16q + c] in chunk c), B = Q (Q[row r][16q + c]); D[i] = S[key 4q + i][row r]
+//   O:  A = V  (V[key 4q + c][4r + t] for dim tile t), B = P (P[row r][key 4q + c] = the lane's own D[c] of S);
+//       D_t[i] = O[dim 16q + 4i + t][row r]  ->  the lane owns out[row r][16q .. 16q + 16)
+// so no value ever crosses lanes except the row maximum (two shuffles per tile and head).  Rows of a tile may belong to
+// different slots (utterance boundaries in the packed prompt): one pass per distinct slot, the other rows masked.
+template <int G>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnDev p, int n_rows) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  // G = query heads per wave (consecutive heads of one kv group): blockIdx.y counts groups of G query heads
+  // The workgroup's 4 waves share the 16 rows and take every 4th key tile each (a causal row tile late in a long prompt
+  // has many: the critical path of the launch); their (max, sum, O) partials are merged through LDS in fixed order.
+  __shared__ float merge[4][64][G * 18];
+  const int hq0 = blockIdx.y * G, kvh = hq0 / (p.n_q_heads / p.n_kv_heads), row0 = blockIdx.x * 16;
+  const int HD = p.n_q_heads * 64, row = row0 + r;
+  const bool in_range = row < n_rows;
+  const int pos = in_range ? p.row_pos[row] : -1;
+  const int slot = in_range ? p.row_slot[row] : -1;
+  const bool valid = in_range && pos >= 0 && pos < p.cache_len;
+  const int jlo = (p.window > 0 && pos + 1 > p.window) ? pos + 1 - p.window : 0;
+
+  float qf[G][16];  // Q[row r][head g][16q .. 16q + 16), pre-scaled by 1/8
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const float* qp = p.q + (long)(valid ? row : 0) * HD + (hq0 + g) * 64 + q * 16;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const float4 t = valid ? *reinterpret_cast<const float4*>(qp + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      qf[g][c4 * 4 + 0] = t.x * 0.125f; qf[g][c4 * 4 + 1] = t.y * 0.125f; qf[g][c4 * 4 + 2] = t.z * 0.125f; qf[g][c4 * 4 + 3] = t.w * 0.125f;
+    }
+  }
+  f32x4 o[G][4];  // o[g][t][i] = O[dim 16q + 4i + t][row r]
+  float mrow[G], lpart[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    mrow[g] = -INFINITY; lpart[g] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o[g][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  unsigned long long todo = __ballot(valid);  // rows whose slot has not been processed yet
+  while (todo != 0ull) {
+    const int leader = __ffsll((long long)todo) - 1;  // lanes 0..15 carry the rows: the lowest pending one picks the slot
+    const int sl = __shfl(slot, leader);
+    const bool mine = valid && slot == sl;
+    todo &= ~__ballot(mine);
+    int lo = mine ? jlo : 0x7fffffff, hi = mine ? pos : -1;
+#pragma unroll
+    for (int ofs = 8; ofs > 0; ofs >>= 1) {  // over the 16 rows (all four q copies hold the same values)
+      lo = min(lo, __shfl_xor(lo, ofs));
+      hi = max(hi, __shfl_xor(hi, ofs));
+    }
+    const long cbase = (((long)sl * p.n_kv_heads + kvh) * p.cache_len) * 64;
+    // K[key j0 + r][16q .. +16) and V[key j0 + 4q + c][4r .. +4), c = 0..3; the next tile's rows are requested before
+    // the current tile is consumed (one wave per SIMD at most: nothing else would hide the load latency)
+    float4 kn[4], vn[4];
+    auto fetch_tile = [&](int j0) {
+      const int jk = j0 + r;
+      const float* kp = p.kc + cbase + (long)jk * 64 + q * 16;
+      const bool okk = jk <= hi;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) kn[c4] = okk ? *reinterpret_cast<const float4*>(kp + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int jv = j0 + 4 * q + c;
+        vn[c] = jv <= hi ? *reinterpret_cast<const float4*>(p.vc + cbase + (long)jv * 64 + r * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    fetch_tile((lo & ~15) + 16 * wave);
+    for (int j0 = (lo & ~15) + 16 * wave; j0 <= hi; j0 += 64) {
+      float kf[16];
+      float4 vf[4];
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        kf[c4 * 4 + 0] = kn[c4].x; kf[c4 * 4 + 1] = kn[c4].y; kf[c4 * 4 + 2] = kn[c4].z; kf[c4 * 4 + 3] = kn[c4].w;
+        vf[c4] = vn[c4];
+      }
+      if (j0 + 64 <= hi) fetch_tile(j0 + 64);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 16; ++c) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c], qf[g][c], s, 0, 0, 0);
+        // s[i] = score of row r against key j0 + 4q + i; mask by this row's slot / causal range
+        float sc[4];
+        float bm = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int j = j0 + 4 * q + i;
+          sc[i] = (mine && j >= jlo && j <= pos) ? s[i] : -INFINITY;
+          bm = fmaxf(bm, sc[i]);
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 16));
+        bm = fmaxf(bm, __shfl_xor(bm, 32));
+        const float mn = fmaxf(mrow[g], bm);
+        const float rs = mn > -INFINITY ? __expf(mrow[g] - mn) : 1.f;  // exp(-inf - finite) = 0 on a row's first tile
+        float pr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pr[i] = mn > -INFINITY ? __expf(sc[i] - mn) : 0.f;
+        lpart[g] = lpart[g] * rs + ((pr[0] + pr[1]) + (pr[2] + pr[3]));
+        mrow[g] = mn;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          f32x4 acc = o[g][t];
+          acc[0] *= rs; acc[1] *= rs; acc[2] *= rs; acc[3] *= rs;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t == 0 ? vf[0].x : t == 1 ? vf[0].y : t == 2 ? vf[0].z : vf[0].w, pr[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t == 0 ? vf[1].x : t == 1 ? vf[1].y : t == 2 ? vf[1].z : vf[1].w, pr[1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t == 0 ? vf[2].x : t == 1 ? vf[2].y : t == 2 ? vf[2].z : vf[2].w, pr[2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t == 0 ? vf[3].x : t == 1 ? vf[3].y : t == 2 ? vf[3].z : vf[3].w, pr[3], acc, 0, 0, 0);
+          o[g][t] = acc;
+        }
+      }
+    }
+  }
+
+  // merge the 4 waves' partials (same lane = same row and columns in every wave), then normalise and store:
+  // the lane owns out[row r][head g][16q .. 16q + 16)
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float* mp = &merge[wave][lane][g * 18];
+    mp[0] = mrow[g]; mp[1] = lpart[g];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mp[2 + t * 4 + i] = o[g][t][i];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float gm = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) gm = fmaxf(gm, merge[w][lane][g * 18]);
+    float l = 0.f;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* mp = &merge[w][lane][g * 18];
+      const float f = mp[0] > -INFINITY ? __expf(mp[0] - gm) : 0.f;
+      l = fmaf(mp[1], f, l);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = fmaf(mp[2 + j], f, acc[j]);
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = valid ? 1.0f / l : 0.f;
+    if (!in_range) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = (hq0 + g) * 64 + 16 * q + 4 * i;
+      const float ox = valid ? __fmul_rn(acc[i], inv) : 0.f, oy = valid ? __fmul_rn(acc[4 + i], inv) : 0.f;
+      const float oz = valid ? __fmul_rn(acc[8 + i], inv) : 0.f, ow = valid ? __fmul_rn(acc[12 + i], inv) : 0.f;
+      if (p.out) *reinterpret_cast<float4*>(p.out + (long)row * HD + k) = make_float4(ox, oy, oz, ow);
+      if (p.out_x3) x3_emit4(p.out_x3, row, k, HD >> 5, ox, oy, oz, ow);
+    }
+  }
+}
+
 // Caches of at most 16 entries (the depth transformer's per-frame cache, lm/generate.py:112): one wave
 // per (row, kv head), all K/V rows loaded up front, no LDS and no barrier -- the kernel is a single
 // memory round trip plus wave shuffles.
@@ -435,6 +599,13 @@ static int launch_attention_once(const float* q, const float* kc, const float* v
   // G > 1 (prompt prefill) the per-wave arithmetic of 4 x G heads outweighs the saved traffic (measured 103 vs 76 us).
   if (G == 1 && (long)n_rows * n_kv_heads >= 1024) {
     hipLaunchKernelGGL(attn_rows4_kernel<1>, dim3((n_rows + 15) / 16, n_kv_heads), dim3(256), 0, stream, d, n_rows);
+    ST_CHECK_HIP(hipGetLastError());
+    return SMOLTTS_OK;
+  }
+  if (G > 1 && (long)n_rows * n_kv_heads >= 1024 && getenv("SMOLTTS_NO_MFMA_ATTN") == nullptr) {  // prompt prefill
+    // one query head per wave: the longest row tile (the critical path of the launch) is G times shorter, and the K / V
+    // tiles re-read by the G waves of a kv group come from L2
+    hipLaunchKernelGGL(attn_prefill_kernel<1>, dim3((n_rows + 15) / 16, n_q_heads), dim3(256), 0, stream, d, n_rows);
     ST_CHECK_HIP(hipGetLastError());
     return SMOLTTS_OK;
   }

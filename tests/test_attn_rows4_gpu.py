@@ -34,11 +34,12 @@ def ref_attention(q, kc, vc, pos, slot, Hq, window):
     return out
 
 
-@pytest.mark.parametrize("Hq,Hkv,window", [(8, 8, 0), (8, 8, 50), (4, 4, 7), (12, 4, 0)])  # the last one: G = 3 takes the per-row kernel
+# G = 1: four rows per wave; G > 1: the matrix-core prefill kernel
+@pytest.mark.parametrize("Hq,Hkv,window", [(8, 8, 0), (8, 8, 50), (4, 4, 7), (12, 4, 0), (9, 3, 0), (6, 3, 20), (8, 2, 0), (12, 4, 5)])
 def test_packed_prompts(ops, Hq, Hkv, window):
     g = torch.Generator().manual_seed(Hq + window)
     lengths = [1, 2, 3, 5, 67, 130, 4, 33, 64, 1, 95]  # utterance boundaries at every residue mod 4
-    lengths += [40] * ((1100 // Hkv - sum(lengths)) // 40 + 1)  # enough rows for the many-row path
+    lengths += [40] * max(0, (1100 // Hkv - sum(lengths)) // 40 + 1)  # enough rows for the many-row path
     slots, cache_len = len(lengths), 140
     kc, vc = torch.randn(slots, Hkv, cache_len, 64, generator=g), torch.randn(slots, Hkv, cache_len, 64, generator=g)
     order = torch.randperm(slots, generator=g).tolist()  # packed in an arbitrary slot order
