@@ -172,145 +172,7 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
   }
 }
 
-// Many rows (the codec transformer): one wave per (4 consecutive rows, kv head).  Consecutive rows
-// are consecutive positions of one slot (except where two utterances meet), so every K / V row the wave loads
-// serves up to 4 query rows x G heads: a quarter of the L2 traffic of one workgroup per row, no LDS, no barrier.
-// Rows of another slot inside the group of 4 are handled in a further pass over that slot's cache.
-template <int G>
-__global__ __launch_bounds__(256) void attn_rows4_kernel(AttnDev p, int n_rows) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int kk = lane >> 4, dl = lane & 15;
-  const int h = blockIdx.y, row0 = (blockIdx.x * 4 + wave) * 4;
-  if (row0 >= n_rows) return;
-  const int HD = p.n_q_heads * 64;
-  int pos[4], slot[4];
-  bool todo[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = row0 + i;
-    const bool in_range = r < n_rows;
-    pos[i] = in_range ? p.row_pos[r] : -1;
-    slot[i] = in_range ? p.row_slot[r] : -1;
-    todo[i] = in_range && pos[i] >= 0 && pos[i] < p.cache_len;
-    if (in_range && !todo[i]) {  // nothing cached for this row: defined output
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const int k = (h * G + g) * 64 + dl * 4;
-        if (kk == 0) {
-          if (p.out) *reinterpret_cast<float4*>(p.out + (long)r * HD + k) = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (p.out_x3) x3_emit4(p.out_x3, r, k, HD >> 5, 0.f, 0.f, 0.f, 0.f);
-        }
-      }
-    }
-  }
-  for (int s = 0; s < 4; ++s) {  // one pass per distinct slot among the 4 rows (wave-uniform control flow throughout)
-    if (!todo[s]) continue;
-    const int sl = slot[s];
-    bool in[4];
-    int jlo[4];
-    int lo = 0x7fffffff, hi = -1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      in[i] = todo[i] && slot[i] == sl;
-      jlo[i] = (p.window > 0 && pos[i] + 1 > p.window) ? pos[i] + 1 - p.window : 0;
-      if (in[i]) {
-        todo[i] = false;
-        lo = jlo[i] < lo ? jlo[i] : lo;
-        hi = pos[i] > hi ? pos[i] : hi;
-      }
-    }
-    float4 qv[4][G], acc[4][G];
-    float mx[4][G], den[4][G];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in[i]) t = *reinterpret_cast<const float4*>(p.q + (long)(row0 + i) * HD + (h * G + g) * 64 + dl * 4);
-        qv[i][g] = make_float4(t.x * 0.125f, t.y * 0.125f, t.z * 0.125f, t.w * 0.125f);
-        acc[i][g] = make_float4(0.f, 0.f, 0.f, 0.f);
-        mx[i][g] = -INFINITY;
-        den[i][g] = 0.f;
-      }
-    const long cbase = (((long)sl * p.n_kv_heads + h) * p.cache_len) * 64 + dl * 4;
-    const float* K = p.kc + cbase;
-    const float* V = p.vc + cbase;
-    for (int jb = lo; jb <= hi; jb += 4 * ATT_UN) {  // 32 consecutive keys per pass: lane group kk takes jb + 4u + kk
-      float4 kv[ATT_UN], vv[ATT_UN];
-#pragma unroll
-      for (int u = 0; u < ATT_UN; ++u) {
-        const int j = jb + 4 * u + kk;
-        const bool ok = j <= hi;
-        kv[u] = ok ? *reinterpret_cast<const float4*>(K + (long)j * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
-        vv[u] = ok ? *reinterpret_cast<const float4*>(V + (long)j * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (!in[i]) continue;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          float sc[ATT_UN];
-          float bm = -INFINITY;
-#pragma unroll
-          for (int u = 0; u < ATT_UN; ++u) {
-            const int j = jb + 4 * u + kk;
-            float t = qv[i][g].x * kv[u].x;
-            t = fmaf(qv[i][g].y, kv[u].y, t);
-            t = fmaf(qv[i][g].z, kv[u].z, t);
-            t = fmaf(qv[i][g].w, kv[u].w, t);
-            t = row16_sum(t);
-            sc[u] = (j >= jlo[i] && j <= pos[i]) ? t : -INFINITY;  // causal / window mask of this row
-            bm = fmaxf(bm, sc[u]);
-          }
-          if (bm > -INFINITY) {  // uniform inside the 16-lane group
-            const float mn = fmaxf(mx[i][g], bm);
-            const float rs = __expf(mx[i][g] - mn);
-            float d = den[i][g] * rs;
-            float4 a = make_float4(acc[i][g].x * rs, acc[i][g].y * rs, acc[i][g].z * rs, acc[i][g].w * rs);
-#pragma unroll
-            for (int u = 0; u < ATT_UN; ++u) {
-              const float e = __expf(sc[u] - mn);
-              d += e;
-              a.x = fmaf(e, vv[u].x, a.x); a.y = fmaf(e, vv[u].y, a.y); a.z = fmaf(e, vv[u].z, a.z); a.w = fmaf(e, vv[u].w, a.w);
-            }
-            mx[i][g] = mn; den[i][g] = d; acc[i][g] = a;
-          }
-        }
-      }
-    }
-    // merge the 4 lane groups (fixed order: xor 16, then xor 32), normalise, store
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (!in[i]) continue;
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        float m_ = mx[i][g], d_ = den[i][g];
-        float4 a_ = acc[i][g];
-#pragma unroll
-        for (int o = 16; o <= 32; o <<= 1) {
-          const float om = __shfl_xor(m_, o), od = __shfl_xor(d_, o);
-          const float ox = __shfl_xor(a_.x, o), oy = __shfl_xor(a_.y, o), oz = __shfl_xor(a_.z, o), ow = __shfl_xor(a_.w, o);
-          const float mn = fmaxf(m_, om);
-          const float sa = mn > -INFINITY ? __expf(m_ - mn) : 0.f, sb = mn > -INFINITY ? __expf(om - mn) : 0.f;
-          d_ = d_ * sa + od * sb;
-          a_ = make_float4(a_.x * sa + ox * sb, a_.y * sa + oy * sb, a_.z * sa + oz * sb, a_.w * sa + ow * sb);
-          m_ = mn;
-        }
-        if (kk == 0) {
-          const float inv = 1.0f / d_;
-          const int k = (h * G + g) * 64 + dl * 4;
-          const int r = row0 + i;
-          // rounded once (no contraction into the X3 split), so that the fp32 and the X3 outputs are the same numbers
-          const float ox = __fmul_rn(a_.x, inv), oy = __fmul_rn(a_.y, inv), oz = __fmul_rn(a_.z, inv), ow = __fmul_rn(a_.w, inv);
-          if (p.out) *reinterpret_cast<float4*>(p.out + (long)r * HD + k) = make_float4(ox, oy, oz, ow);
-          if (p.out_x3) x3_emit4(p.out_x3, r, k, HD >> 5, ox, oy, oz, ow);
-        }
-      }
-    }
-  }
-}
-
-// Prompt prefill with GQA (many rows, G > 1): flash-style attention on the fp32 matrix cores.  One workgroup per
+// Many rows (prompt prefill, the codec transformer): flash-style attention on the fp32 matrix cores.  One workgroup per
 // (16 consecutive rows, G query heads); keys in tiles of 16 dealt round-robin to its 4 waves; per tile and query head 16 v_mfma_f32_16x16x4_f32 for
 // S = K Q^T and 16 for O += V^T P, every K / V tile loaded once for 16 rows x G heads (exact fp32 products, fp32
 // accumulation: the same arithmetic class as the per-row kernel).  Fragment bookkeeping, lane l = 16 q + r:
@@ -595,14 +457,7 @@ static int launch_attention_once(const float* q, const float* kc, const float* v
     ST_CHECK_HIP(hipGetLastError());
     return SMOLTTS_OK;
   }
-  // many rows without GQA sharing (the codec transformer): 4 rows per wave share every K / V row they load.  With
-  // G > 1 (prompt prefill) the per-wave arithmetic of 4 x G heads outweighs the saved traffic (measured 103 vs 76 us).
-  if (G == 1 && (long)n_rows * n_kv_heads >= 1024) {
-    hipLaunchKernelGGL(attn_rows4_kernel<1>, dim3((n_rows + 15) / 16, n_kv_heads), dim3(256), 0, stream, d, n_rows);
-    ST_CHECK_HIP(hipGetLastError());
-    return SMOLTTS_OK;
-  }
-  if (G > 1 && (long)n_rows * n_kv_heads >= 1024 && getenv("SMOLTTS_NO_MFMA_ATTN") == nullptr) {  // prompt prefill
+  if ((long)n_rows * n_kv_heads >= 1024 && getenv("SMOLTTS_NO_MFMA_ATTN") == nullptr) {  // prompt prefill, codec transformer
     // one query head per wave: the longest row tile (the critical path of the launch) is G times shorter, and the K / V
     // tiles re-read by the G waves of a kv group come from L2
     hipLaunchKernelGGL(attn_prefill_kernel<1>, dim3((n_rows + 15) / 16, n_q_heads), dim3(256), 0, stream, d, n_rows);

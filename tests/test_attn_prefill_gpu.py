@@ -1,4 +1,4 @@
-"""Many-row attention (4 rows per wave when there is no GQA sharing: the codec transformer; per row otherwise): packed utterances with boundaries inside
+"""Many-row attention on the matrix cores (prompt prefill, codec transformer): packed utterances with boundaries inside
 groups of four rows, arbitrary row->slot orders, windows, rows without cache, X3 output."""
 import pytest
 import torch
@@ -34,7 +34,7 @@ def ref_attention(q, kc, vc, pos, slot, Hq, window):
     return out
 
 
-# G = 1: four rows per wave; G > 1: the matrix-core prefill kernel
+# with and without GQA, windows, utterance boundaries at every residue
 @pytest.mark.parametrize("Hq,Hkv,window", [(8, 8, 0), (8, 8, 50), (4, 4, 7), (12, 4, 0), (9, 3, 0), (6, 3, 20), (8, 2, 0), (12, 4, 5)])
 def test_packed_prompts(ops, Hq, Hkv, window):
     g = torch.Generator().manual_seed(Hq + window)
