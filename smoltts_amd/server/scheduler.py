@@ -30,6 +30,7 @@ class _Request:
     emitted: int = 0
     msess: object = None
     pcm: object = None
+    pending: list = field(default_factory=list)  # blocking requests: audio-code columns awaiting one batched codec call
 
 
 class BatchScheduler:
@@ -56,6 +57,10 @@ class BatchScheduler:
         self._free: List[int] = list(range(max_batch))
         self._stop = threading.Event()
         self._started = False
+        self._codec_pool: Dict[int, list] = {}  # chunk size -> idle one-slot codec sessions (their slabs are re-used)
+        self._finished: List[_Request] = []     # complete blocking utterances waiting for their (batched) codec pass
+        self._finished_age = 0
+        self._batch_codec = None                # one multi-slot codec session for those passes
         self._thread = threading.Thread(target=self._run, name="smoltts-scheduler", daemon=True)
         self._thread.start()
 
@@ -81,6 +86,13 @@ class BatchScheduler:
     def close(self) -> None:
         self._stop.set()
         self._thread.join(timeout=30)
+        for pool in self._codec_pool.values():
+            for sess in pool:
+                sess.close()
+        self._codec_pool.clear()
+        if self._batch_codec is not None:
+            self._batch_codec.close()
+            self._batch_codec = None
         self.session.close()
 
     # ------------------------------------------------------------------ worker
@@ -114,9 +126,33 @@ class BatchScheduler:
             self.session.prefill([r.prompt for r in new], slots=[r.slot for r in new], stop_on_eos=True)
         self._started = True
         for r in new:
-            r.msess = MimiSession(self.tts.codec, max_batch=1, max_chunk_frames=max(self.tick, 1) + 1)
-            r.msess.reset()
+            # streaming answers decode every tick through a one-slot codec session; blocking answers are decoded when
+            # the utterance is complete, several utterances per codec pass (_decode_finished)
+            r.msess = self._codec_session(max(self.tick, 1) + 1) if r.stream else None
             self._active[r.slot] = r
+
+    def _codec_session(self, chunk: int):
+        from ..engine import MimiSession
+
+        pool = self._codec_pool.setdefault(chunk, [])
+        sess = pool.pop() if pool else MimiSession(self.tts.codec, max_batch=1, max_chunk_frames=chunk)
+        sess.reset()
+        return sess
+
+    def _release_codec(self, sess) -> None:
+        self._codec_pool.setdefault(sess.chunk, []).append(sess)
+
+    def _decode_frames(self, r: _Request, cols: np.ndarray) -> None:
+        """cols (k, nq) audio codes of consecutive frames of request r -> PCM chunks on its queue."""
+        torch = self._torch
+        nq = cols.shape[1]
+        for i in range(0, cols.shape[0], r.msess.chunk):
+            part = np.ascontiguousarray(cols[i: i + r.msess.chunk])
+            k = part.shape[0]
+            chunk = torch.from_numpy(part).reshape(1, k, nq).cuda()
+            pcm = torch.empty(1, k * 1920, dtype=torch.float32, device="cuda")
+            r.msess.decode_chunk(chunk, 0, k, pcm, code_offset=0)
+            r.out.put(pcm.cpu().numpy().reshape(-1))
 
     def _drain(self) -> None:
         torch = self._torch
@@ -128,19 +164,57 @@ class BatchScheduler:
             # lm/generate.py:196-207); streaming requests decode every frame (__init__.py:88-92)
             tc = self.tts.token_config
             sel = [f for f in range(r.emitted, n) if r.stream or tc.semantic_start_id <= codes[slot, f, 0] <= tc.semantic_end_id]
-            for i in range(0, len(sel), r.msess.chunk):
-                part = sel[i: i + r.msess.chunk]
-                k = len(part)
-                chunk = torch.from_numpy(np.ascontiguousarray(codes[slot, part][:, -nq:])).reshape(1, k, nq).cuda()
-                pcm = torch.empty(1, k * 1920, dtype=torch.float32, device="cuda")
-                r.msess.decode_chunk(chunk, 0, k, pcm, code_offset=0)
-                r.out.put(pcm.cpu().numpy().reshape(-1))
             r.emitted = n
-            if done[slot] or r.emitted >= r.max_new_tokens + 1:
-                r.msess.close()
-                r.out.put(None)
+            finished = bool(done[slot]) or r.emitted >= r.max_new_tokens + 1
+            if sel:
+                cols = codes[slot, sel][:, -nq:].astype(np.int32)
+                if r.stream:
+                    self._decode_frames(r, cols)
+                else:
+                    r.pending.append(cols)
+            if finished:
                 del self._active[slot]
                 self._free.append(slot)
+                if r.stream:
+                    self._release_codec(r.msess)
+                    r.msess = None
+                    r.out.put(None)
+                else:
+                    self._finished.append(r)
+
+    CODEC_BATCH, CODEC_CHUNK = 8, 64
+
+    def _decode_finished(self, force: bool) -> None:
+        """Codec pass over up to CODEC_BATCH complete blocking utterances at once (each in its own slot from position 0,
+        the shorter ones padded at the end: the decoder is causal, so the padding cannot reach their samples).  Runs when
+        enough utterances wait, when they have waited two ticks, or when nothing else is going on."""
+        if not self._finished:
+            return
+        self._finished_age += 1
+        if not (force or len(self._finished) >= self.CODEC_BATCH or self._finished_age >= 2):
+            return
+        torch = self._torch
+        from ..engine import MimiSession
+
+        if self._batch_codec is None:
+            self._batch_codec = MimiSession(self.tts.codec, max_batch=self.CODEC_BATCH, max_chunk_frames=self.CODEC_CHUNK)
+        nq = self.tts.config.num_codebooks
+        while self._finished:
+            batch, self._finished = self._finished[: self.CODEC_BATCH], self._finished[self.CODEC_BATCH:]
+            cols = [np.concatenate(r.pending) if r.pending else np.zeros((0, nq), np.int32) for r in batch]
+            F = max(c.shape[0] for c in cols)
+            if F > 0:
+                grid = np.zeros((len(batch), F, nq), np.int32)
+                for b, c in enumerate(cols):
+                    grid[b, : c.shape[0]] = c
+                pcm = self._batch_codec.decode(torch.from_numpy(grid).cuda()).cpu().numpy()
+                for b, (r, c) in enumerate(zip(batch, cols)):
+                    if c.shape[0]:
+                        r.out.put(pcm[b, : c.shape[0] * 1920].copy())
+            for r in batch:
+                r.pending = []
+                r.out.put(None)
+        self._finished_age = 0
 
     def _run(self) -> None:
         try:
@@ -154,9 +228,10 @@ class BatchScheduler:
                     continue
                 self._drain()           # frame 0 of freshly admitted requests / last tick's frames
                 if self._active:
-                    self.session.decode(self.tick)
+                    self.session.decode(self.tick)  # asynchronous: the codec pass below queues behind it
+                self._decode_finished(force=not self._active)
         except Exception as e:  # engine failure: fail every waiter loudly
-            for r in list(self._active.values()):
+            for r in list(self._active.values()) + self._finished:
                 r.out.put(e)
             while not self._pending.empty():
                 self._pending.get_nowait().out.put(e)

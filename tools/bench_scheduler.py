@@ -1,0 +1,43 @@
+"""Sustained serving throughput of the continuous-batching scheduler (SURVEY.md §8d EOS variant): 128 requests with
+frame budgets U{64..384} (seed 1) through 32 slots, smoltts_byte_150m synthetic weights, greedy, blocking responses."""
+import sys
+import threading
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from bench import make_prompts  # noqa: E402,F401
+from smoltts_amd import SmolTTS  # noqa: E402
+from smoltts_amd.codec.synthetic import synthetic_mimi_state  # noqa: E402
+from smoltts_amd.config import GenerationSettings  # noqa: E402
+from smoltts_amd.server.scheduler import BatchScheduler  # noqa: E402
+from smoltts_amd.synthetic import named_config, synthetic_lm_state  # noqa: E402
+
+n_req = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+tick = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+cfg = named_config("smoltts_byte_150m")
+tts = SmolTTS(state=synthetic_lm_state(cfg, seed=0), config=cfg, mimi_state=synthetic_mimi_state(seed=0))
+rng = np.random.default_rng(1)
+budgets = rng.integers(64, 385, size=n_req)
+rng2 = np.random.default_rng(2)
+texts = ["".join(chr(int(c)) for c in rng2.integers(32, 127, size=int(rng2.integers(40, 161)))) for _ in range(n_req)]
+sched = BatchScheduler(tts, max_batch=32, frames_per_tick=tick, generation_settings=GenerationSettings.greedy(max_new_tokens=400))
+sched.synthesize("warm up", max_new_tokens=8)
+samples = [0] * n_req
+
+
+def worker(i):
+    samples[i] = sched.synthesize(texts[i], "heart", max_new_tokens=int(budgets[i])).shape[0]
+
+
+t0 = time.perf_counter()
+threads = [threading.Thread(target=worker, args=(i,)) for i in range(n_req)]
+for t in threads:
+    t.start()
+for t in threads:
+    t.join()
+dt = time.perf_counter() - t0
+frames = sum(samples) // 1920
+print(f"{n_req} requests, {frames} frames of audio in {dt:.2f} s -> {frames / dt:.0f} frames/s ({frames / dt / 12.5:.0f}x real time), tick {tick}")
+sched.close()
