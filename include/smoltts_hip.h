@@ -144,6 +144,14 @@ int smoltts_lm_prefill_chunk(SmolttsSession* s, const int32_t* grid_dev, const i
                              const int32_t* row_pos_dev, int32_t n_rows, const int32_t* slots_host,
                              const int32_t* last_row_host, int32_t n_slots, void* stream);
 
+/* Prefill without the frame-0 tail (continuous batching: a decode call follows anyway): fills the KV rows of the prompt
+ * and arms the listed slots so that the *next decode frame* takes the last prompt column as its input and emits the
+ * slot's frame 0.  Same arguments as smoltts_lm_prefill; the ids produced are the same. */
+int smoltts_lm_prefill_deferred(SmolttsSession* s, const int32_t* grid_dev, const int32_t* row_slot_dev,
+                                const int32_t* row_pos_dev, int32_t n_rows, const int32_t* slots_host,
+                                const int32_t* last_row_host, int32_t n_slots, int32_t stop_on_eos,
+                                void* stream);
+
 /* Decode n_frames further frames for every slot of the session: each frame feeds the previous
  * column back (slow step at the slot's next position), then slow head + n_fast depth steps, all
  * greedy and on device; the frame loop is a captured hipGraph replayed n_frames times.  Slots that

@@ -53,6 +53,8 @@ struct SmolttsSession {
   int* codes;                // [B][max_frames][1+n_fast]
   // host staging (pinned)
   int* h_stage;
+  hipEvent_t stage_ev;         // recorded behind the async copies out of h_stage
+  bool stage_ev_live;
   hipGraphExec_t graph_exec;   // one decode frame (slow step + tail)
   bool graph_ready;
   hipGraphExec_t tail_exec;    // the tail alone (slow head + depth steps + commit) as run after a prefill
@@ -140,6 +142,21 @@ __global__ void slot_reset_kernel(int B, int n_slots, const int* slots, const in
     pos[b] = row_pos[last_row[hit]] + 1;
     frames[b] = 0; done[b] = 0; margin[b] = INFINITY;
   }
+}
+
+// Deferred start: the prompt's KV rows are in place; the slot is armed so that the next decode frame takes the last prompt
+// column as its slow-step input at that column's position and emits frame 0 in its own tail (no separate tail launch).
+__global__ void slot_start_kernel(int B, int H, int n_slots, const int* slots, const int* last_row, const int* row_pos,
+                                  const int* grid, int* pos, int* frames, int* done, float* margin, int* cur_col) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  for (int i = 0; i < n_slots; ++i)
+    if (slots[i] == b) {
+      const int lr = last_row[i];
+      pos[b] = row_pos[lr];
+      frames[b] = 0; done[b] = 0; margin[b] = INFINITY;
+      for (int k = 0; k < H; ++k) cur_col[b * H + k] = grid[(long)lr * H + k];
+    }
 }
 
 // Chunked prefill: the listed slots stay idle (done, masked) and their position counter is parked just
@@ -341,6 +358,18 @@ int run_decode_frame(SmolttsSession* s, hipStream_t st) {
   return run_tail(s, /*advance_pos=*/1, st);
 }
 
+// Slot / last-row lists of a prefill call -> device, through the session's pinned staging buffer.  Only the previous
+// upload is waited for (an event), never the stream: a serving loop calls this while earlier frames are still running.
+int stage_upload(SmolttsSession* s, const int32_t* slots_host, const int32_t* last_row_host, int n_slots, hipStream_t st) {
+  if (s->stage_ev_live) ST_CHECK_HIP(hipEventSynchronize(s->stage_ev));
+  for (int i = 0; i < n_slots; ++i) { s->h_stage[i] = slots_host[i]; s->h_stage[s->B + i] = last_row_host[i]; }
+  ST_CHECK_HIP(hipMemcpyAsync(s->stage_slots, s->h_stage, sizeof(int) * n_slots, hipMemcpyHostToDevice, st));
+  ST_CHECK_HIP(hipMemcpyAsync(s->stage_last, s->h_stage + s->B, sizeof(int) * n_slots, hipMemcpyHostToDevice, st));
+  ST_CHECK_HIP(hipEventRecord(s->stage_ev, st));
+  s->stage_ev_live = true;
+  return SMOLTTS_OK;
+}
+
 void drop_graphs(SmolttsSession* s) {
   if (s->graph_ready) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_ready = false; }
   if (s->tail_ready) { (void)hipGraphExecDestroy(s->tail_exec); s->tail_ready = false; }
@@ -473,6 +502,12 @@ int smoltts_session_create(SmolttsEngine* e, void* slab_dev, size_t slab_bytes, 
     set_error("session_create: hipHostMalloc failed");
     return SMOLTTS_E_HIP;
   }
+  if (hipEventCreateWithFlags(&s->stage_ev, hipEventDisableTiming) != hipSuccess) {
+    (void)hipHostFree(s->h_stage);
+    delete s;
+    set_error("session_create: hipEventCreate failed");
+    return SMOLTTS_E_HIP;
+  }
   hipLaunchKernelGGL(init_state_kernel, dim3((max_batch + 63) / 64), dim3(64), 0, 0, max_batch, e->cfg.n_fast, s->iota,
                      s->fastpos, s->pos, s->frames, s->done, s->mask, s->margin, s->cur_col, s->new_col);
   hipError_t err = hipGetLastError();
@@ -490,6 +525,7 @@ int smoltts_session_create(SmolttsEngine* e, void* slab_dev, size_t slab_bytes, 
 void smoltts_session_destroy(SmolttsSession* s) {
   if (!s) return;
   drop_graphs(s);
+  if (s->stage_ev) (void)hipEventDestroy(s->stage_ev);
   if (s->h_stage) (void)hipHostFree(s->h_stage);
   delete s;
 }
@@ -510,11 +546,7 @@ int smoltts_lm_prefill(SmolttsSession* s, const int32_t* grid_dev, const int32_t
   const SmolttsLMConfig& c = e->cfg;
   if (s->stop_on_eos != stop_on_eos) drop_graphs(s);  // the flag is baked into the captured commit nodes
   s->stop_on_eos = stop_on_eos;
-  // the staging buffer may still be read by an earlier async copy on this stream
-  ST_CHECK_HIP(hipStreamSynchronize(st));
-  for (int i = 0; i < n_slots; ++i) { s->h_stage[i] = slots_host[i]; s->h_stage[s->B + i] = last_row_host[i]; }
-  ST_CHECK_HIP(hipMemcpyAsync(s->stage_slots, s->h_stage, sizeof(int) * n_slots, hipMemcpyHostToDevice, st));
-  ST_CHECK_HIP(hipMemcpyAsync(s->stage_last, s->h_stage + s->B, sizeof(int) * n_slots, hipMemcpyHostToDevice, st));
+  ST_TRY(stage_upload(s, slots_host, last_row_host, n_slots, st));
   hipLaunchKernelGGL(slot_reset_kernel, dim3((s->B + 63) / 64), dim3(64), 0, st, s->B, n_slots, s->stage_slots, s->stage_last,
                      row_pos_dev, s->pos, s->frames, s->done, s->mask, s->margin);
   ST_CHECK_HIP(hipGetLastError());
@@ -552,15 +584,37 @@ int smoltts_lm_prefill_chunk(SmolttsSession* s, const int32_t* grid_dev, const i
     ST_REQUIRE(last_row_host[i] >= 0 && last_row_host[i] < n_rows, SMOLTTS_E_INVALID, "lm_prefill_chunk: last_row %d out of range", last_row_host[i]);
   }
   hipStream_t st = (hipStream_t)stream;
-  ST_CHECK_HIP(hipStreamSynchronize(st));  // the staging buffer may still be read by an earlier async copy
-  for (int i = 0; i < n_slots; ++i) { s->h_stage[i] = slots_host[i]; s->h_stage[s->B + i] = last_row_host[i]; }
-  ST_CHECK_HIP(hipMemcpyAsync(s->stage_slots, s->h_stage, sizeof(int) * n_slots, hipMemcpyHostToDevice, st));
-  ST_CHECK_HIP(hipMemcpyAsync(s->stage_last, s->h_stage + s->B, sizeof(int) * n_slots, hipMemcpyHostToDevice, st));
+  ST_TRY(stage_upload(s, slots_host, last_row_host, n_slots, st));
   hipLaunchKernelGGL(slot_park_kernel, dim3((s->B + 63) / 64), dim3(64), 0, st, s->B, n_slots, s->stage_slots, s->stage_last, row_pos_dev,
                      s->pos, s->done, s->mask);
   ST_CHECK_HIP(hipGetLastError());
   ST_TRY(embed_rows(s, grid_dev, n_rows, s->xr, st));
   return run_slow_layers(s, s->xr, s->qr, n_rows, row_pos_dev, row_slot_dev, /*publish_hidden=*/false, st);
+}
+
+int smoltts_lm_prefill_deferred(SmolttsSession* s, const int32_t* grid_dev, const int32_t* row_slot_dev, const int32_t* row_pos_dev,
+                                int32_t n_rows, const int32_t* slots_host, const int32_t* last_row_host, int32_t n_slots,
+                                int32_t stop_on_eos, void* stream) {
+  ST_REQUIRE(s && grid_dev && row_slot_dev && row_pos_dev && slots_host && last_row_host, SMOLTTS_E_INVALID,
+             "lm_prefill_deferred: null argument");
+  ST_REQUIRE(n_rows > 0 && n_rows <= s->max_rows, SMOLTTS_E_CAPACITY, "lm_prefill_deferred: %d rows, session holds %d", n_rows, s->max_rows);
+  ST_REQUIRE(n_slots > 0 && n_slots <= s->B, SMOLTTS_E_CAPACITY, "lm_prefill_deferred: %d slots, session holds %d", n_slots, s->B);
+  for (int i = 0; i < n_slots; ++i) {
+    ST_REQUIRE(slots_host[i] >= 0 && slots_host[i] < s->B, SMOLTTS_E_INVALID, "lm_prefill_deferred: slot %d out of range", slots_host[i]);
+    ST_REQUIRE(last_row_host[i] >= 0 && last_row_host[i] < n_rows, SMOLTTS_E_INVALID, "lm_prefill_deferred: last_row %d out of range", last_row_host[i]);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (s->stop_on_eos != stop_on_eos) drop_graphs(s);  // the flag is baked into the captured commit nodes
+  s->stop_on_eos = stop_on_eos;
+  ST_TRY(stage_upload(s, slots_host, last_row_host, n_slots, st));
+  // KV rows of the whole prompt (the last column's row is recomputed by the first decode frame, identically)
+  ST_TRY(embed_rows(s, grid_dev, n_rows, s->xr, st));
+  ST_TRY(run_slow_layers(s, s->xr, s->qr, n_rows, row_pos_dev, row_slot_dev, /*publish_hidden=*/false, st));
+  hipLaunchKernelGGL(slot_start_kernel, dim3((s->B + 63) / 64), dim3(64), 0, st, s->B, 1 + s->e->cfg.n_fast, n_slots, s->stage_slots,
+                     s->stage_last, row_pos_dev, grid_dev, s->pos, s->frames, s->done, s->margin, s->cur_col);
+  ST_CHECK_HIP(hipGetLastError());
+  s->prefilled = true;
+  return SMOLTTS_OK;
 }
 
 int smoltts_lm_decode(SmolttsSession* s, int32_t n_frames, void* stream) {

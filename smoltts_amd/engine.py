@@ -98,7 +98,7 @@ _EXPORTS = [
     "smoltts_mimi_decode_chunk", "smoltts_k_gemm", "smoltts_k_attention", "smoltts_k_embed", "smoltts_k_argmax",
     "smoltts_k_layernorm", "smoltts_profile_begin", "smoltts_profile_end", "smoltts_k_gemm3", "smoltts_k_x3_pack",
     "smoltts_debug_duplicate", "smoltts_session_drop_graph", "smoltts_session_set_sampling", "smoltts_k_sample",
-    "smoltts_lm_prefill_chunk", "smoltts_mimi_encoder_create", "smoltts_mimi_encoder_destroy", "smoltts_mimi_encode_frames",
+    "smoltts_lm_prefill_chunk", "smoltts_lm_prefill_deferred", "smoltts_mimi_encoder_create", "smoltts_mimi_encoder_destroy", "smoltts_mimi_encode_frames",
     "smoltts_mimi_encode_workspace_bytes", "smoltts_mimi_encode",
 ]
 
@@ -150,6 +150,8 @@ def load_library(path: Optional[Path] = None):
                                      C.c_int32, C.c_void_p, C.c_void_p]
     lib.smoltts_debug_duplicate.argtypes = [C.c_int32, C.c_int32]
     lib.smoltts_session_drop_graph.argtypes = [C.c_void_p]
+    lib.smoltts_lm_prefill_deferred.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                                C.c_int32, C.c_void_p]
     lib.smoltts_lm_prefill_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                              C.c_void_p]
     lib.smoltts_mimi_encoder_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -308,11 +310,12 @@ class LMSession:
         self._keep = None
 
     def prefill(self, prompts: Sequence[np.ndarray], slots: Optional[Sequence[int]] = None, stop_on_eos: bool = True,
-                pos0: Optional[Sequence[int]] = None, final: bool = True) -> None:
+                pos0: Optional[Sequence[int]] = None, final: bool = True, defer_frame0: bool = False) -> None:
         """prompts: one ``(1 + n_fast, T_b)`` int grid per utterance; emits frame 0 of each slot.
 
         Chunked prefill: ``pos0[b]`` is the position of the first column of ``prompts[b]`` (its earlier columns
-        went through previous calls with ``final=False``, which fill the KV cache only and leave the slot idle)."""
+        went through previous calls with ``final=False``, which fill the KV cache only and leave the slot idle).
+        ``defer_frame0``: no frame-0 tail here; the next ``decode`` call emits frame 0 as its first frame (serving loop)."""
         slots = list(range(len(prompts))) if slots is None else list(slots)
         if len(slots) != len(prompts) or len(set(slots)) != len(slots):
             raise ValueError("slots must be distinct and match prompts")
@@ -343,7 +346,10 @@ class LMSession:
         slots_h = (C.c_int32 * len(slots))(*slots)
         last_h = (C.c_int32 * len(slots))(*last)
         self._keep = (grid_d, rslot_d, rpos_d)  # alive until the stream has consumed them
-        if final:
+        if final and defer_frame0:
+            check(self.lib.smoltts_lm_prefill_deferred(self.handle, dptr(grid_d), dptr(rslot_d), dptr(rpos_d), n, slots_h, last_h,
+                                                       len(slots), int(stop_on_eos), current_stream_ptr()), "smoltts_lm_prefill_deferred")
+        elif final:
             check(self.lib.smoltts_lm_prefill(self.handle, dptr(grid_d), dptr(rslot_d), dptr(rpos_d), n, slots_h, last_h,
                                               len(slots), int(stop_on_eos), current_stream_ptr()), "smoltts_lm_prefill")
         else:
@@ -351,7 +357,7 @@ class LMSession:
                                                     len(slots), current_stream_ptr()), "smoltts_lm_prefill_chunk")
 
     def prefill_chunked(self, prompts: Sequence[np.ndarray], slots: Optional[Sequence[int]] = None, stop_on_eos: bool = True,
-                        chunk: int = 128, between=None) -> None:
+                        chunk: int = 128, between=None, defer_frame0: bool = False) -> None:
         """The same result as ``prefill`` with at most ``chunk`` columns per utterance per call; ``between()`` runs
         after every partial call (e.g. a few decode frames for the slots that are already speaking)."""
         slots = list(range(len(prompts))) if slots is None else list(slots)
@@ -367,7 +373,7 @@ class LMSession:
                 done[i] += chunk
             if between is not None:
                 between()
-        self.prefill([g[:, d:] for g, d in zip(prompts, done)], slots, stop_on_eos, pos0=done, final=True)
+        self.prefill([g[:, d:] for g, d in zip(prompts, done)], slots, stop_on_eos, pos0=done, final=True, defer_frame0=defer_frame0)
 
     def set_sampling(self, temp: float = 0.0, fast_temp: float = 0.0, min_p: float = 0.0, seed: int = 0) -> None:
         """temp / fast_temp <= 0: greedy (default). Takes effect from the next frame."""

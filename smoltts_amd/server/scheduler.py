@@ -3,11 +3,18 @@
 The reference serves one request at a time (its handlers call the model inline,
 mlx_inference/.../server/routes/openai.py:17-28).  Here one worker thread owns an ``LMSession`` with
 ``max_batch`` slots: new requests are prefilled into free slots while the other slots keep decoding
-(``smoltts_lm_prefill`` restarts only the listed slots), every tick decodes a few frames for all slots,
-finished slots (``<|im_end|>`` or frame budget) are released.  Prompts longer than ``prefill_chunk`` columns are
-prefilled in chunks (``smoltts_lm_prefill_chunk``) with a decode tick for the speaking slots between chunks.  Audio is produced per request by its
-own streaming Mimi session, so blocking and streaming responses share one code path and a request's
-PCM is identical to what ``SmolTTS.__call__`` / ``stream`` return for it alone.
+(``smoltts_lm_prefill_deferred`` restarts only the listed slots and leaves frame 0 to the next frame graph), every tick
+decodes a few frames for all slots, finished slots (``<|im_end|>`` or frame budget) are released.  Prompts longer than
+``prefill_chunk`` columns are prefilled in chunks (``smoltts_lm_prefill_chunk``) with a tick for the speaking slots
+between chunks.
+
+The loop is pipelined so that the GPU never waits for Python: tick k is queued, a device-side snapshot of the output ring
+is queued behind it, and *then* the host reads the snapshot of tick k-1 (on a copy stream) and does its bookkeeping while
+tick k runs.  A slot that finished in tick k-1 is therefore refilled in tick k+1 (one tick of that slot is the price).
+Codec work is queued on the same stream behind the ticks and its PCM is fetched on the copy stream when its event has
+fired: a streaming request owns a one-slot codec session and is decoded every tick; a blocking request is decoded when its
+utterance is complete, up to ``CODEC_BATCH`` finished utterances per codec pass.  A request's PCM is identical to what
+``SmolTTS.__call__`` / ``stream`` return for it alone.
 """
 from __future__ import annotations
 
@@ -29,11 +36,14 @@ class _Request:
     slot: int = -1
     emitted: int = 0
     msess: object = None
-    pcm: object = None
-    pending: list = field(default_factory=list)  # blocking requests: audio-code columns awaiting one batched codec call
+    pending: list = field(default_factory=list)  # blocking requests: audio-code columns awaiting their codec pass
+    prompt: object = None
+    first_tick: int = 0  # index of the tick that produces this request's frame 0: older snapshots show the slot's previous tenant
 
 
 class BatchScheduler:
+    CODEC_BATCH, CODEC_CHUNK = 8, 64
+
     def __init__(self, tts, max_batch: int = 32, frames_per_tick: int = 4, generation_settings=None, max_prompt_rows: int = 4096,
                  prefill_chunk: Optional[int] = 128):
         import torch
@@ -56,11 +66,13 @@ class BatchScheduler:
         self._active: Dict[int, _Request] = {}
         self._free: List[int] = list(range(max_batch))
         self._stop = threading.Event()
-        self._started = False
         self._codec_pool: Dict[int, list] = {}  # chunk size -> idle one-slot codec sessions (their slabs are re-used)
         self._finished: List[_Request] = []     # complete blocking utterances waiting for their (batched) codec pass
         self._finished_age = 0
         self._batch_codec = None                # one multi-slot codec session for those passes
+        self._deliveries: List[tuple] = []      # (event, pcm on the device, [(request, first sample, n samples, last?)]) in order
+        self._snaps: List[tuple] = []           # snapshots of the output ring the host has not looked at yet (oldest first)
+        self._tick_no = 0                       # ticks queued so far
         self._thread = threading.Thread(target=self._run, name="smoltts-scheduler", daemon=True)
         self._thread.start()
 
@@ -95,7 +107,7 @@ class BatchScheduler:
             self._batch_codec = None
         self.session.close()
 
-    # ------------------------------------------------------------------ worker
+    # ------------------------------------------------------------------ worker: admission
     def _admit(self) -> None:
         new: List[_Request] = []
         while self._free and not self._pending.empty():
@@ -111,24 +123,21 @@ class BatchScheduler:
             new.append(req)
         if not new:
             return
-        from ..engine import MimiSession
-
         if self.prefill_chunk:
             # long prompts (voice-clone speakers) enter in chunks; the slots already speaking get a tick in between
             def between():
                 if self._active:
-                    self.session.decode(self.tick)
-                    self._drain()
+                    self._tick_and_snapshot()
+                    self._consume_snapshots(keep=1)
 
             self.session.prefill_chunked([r.prompt for r in new], slots=[r.slot for r in new], stop_on_eos=True,
-                                         chunk=self.prefill_chunk, between=between)
+                                         chunk=self.prefill_chunk, between=between, defer_frame0=True)
         else:
-            self.session.prefill([r.prompt for r in new], slots=[r.slot for r in new], stop_on_eos=True)
-        self._started = True
+            # frame 0 of the new slots comes out of the next tick's first frame (no separate tail for all slots)
+            self.session.prefill([r.prompt for r in new], slots=[r.slot for r in new], stop_on_eos=True, defer_frame0=True)
         for r in new:
-            # streaming answers decode every tick through a one-slot codec session; blocking answers are decoded when
-            # the utterance is complete, several utterances per codec pass (_decode_finished)
             r.msess = self._codec_session(max(self.tick, 1) + 1) if r.stream else None
+            r.first_tick = self._tick_no
             self._active[r.slot] = r
 
     def _codec_session(self, chunk: int):
@@ -139,61 +148,89 @@ class BatchScheduler:
         sess.reset()
         return sess
 
-    def _release_codec(self, sess) -> None:
-        self._codec_pool.setdefault(sess.chunk, []).append(sess)
-
-    def _decode_frames(self, r: _Request, cols: np.ndarray) -> None:
-        """cols (k, nq) audio codes of consecutive frames of request r -> PCM chunks on its queue."""
+    # ------------------------------------------------------------------ worker: ticks and snapshots
+    def _tick_and_snapshot(self) -> None:
+        """Queue one tick of frames and, behind it, a device-side copy of the output ring with an event: the host reads
+        that copy later, while the following tick runs."""
         torch = self._torch
-        nq = cols.shape[1]
-        for i in range(0, cols.shape[0], r.msess.chunk):
-            part = np.ascontiguousarray(cols[i: i + r.msess.chunk])
-            k = part.shape[0]
-            chunk = torch.from_numpy(part).reshape(1, k, nq).cuda()
-            pcm = torch.empty(1, k * 1920, dtype=torch.float32, device="cuda")
-            r.msess.decode_chunk(chunk, 0, k, pcm, code_offset=0)
-            r.out.put(pcm.cpu().numpy().reshape(-1))
+        self.session.decode(self.tick)
+        s = self.session
+        snap = (s.codes.clone(), s.n_frames.clone(), s.done.clone(), torch.cuda.Event(), self._tick_no)
+        snap[3].record(torch.cuda.current_stream())
+        self._snaps.append(snap)
+        self._tick_no += 1
 
-    def _drain(self) -> None:
+    def _consume_snapshots(self, keep: int) -> None:
+        """Read all but the ``keep`` newest snapshots (keep=1 in the steady state: the newest belongs to the tick that has
+        only just been queued; its predecessor finished before that tick could start)."""
         torch = self._torch
-        codes, n_frames, done, _ = self.session.fetch()
+        while len(self._snaps) > keep:
+            codes_d, n_d, done_d, ev, tick_no = self._snaps.pop(0)
+            with torch.cuda.stream(self._copy_stream):
+                self._copy_stream.wait_event(ev)
+                codes = codes_d.to("cpu", non_blocking=True)
+                n_frames = n_d.to("cpu", non_blocking=True)
+                done = done_d.to("cpu", non_blocking=True)
+            self._copy_stream.synchronize()
+            self._drain(codes.numpy(), n_frames.numpy(), done.numpy(), tick_no)
+
+    def _drain(self, codes, n_frames, done, tick_no: int) -> None:
         nq = self.tts.config.num_codebooks
+        tc = self.tts.token_config
         for slot, r in list(self._active.items()):
+            if tick_no < r.first_tick:  # the snapshot predates this request: it shows the slot's previous tenant
+                continue
             n = min(int(n_frames[slot]), r.max_new_tokens + 1)
             # blocking requests keep only frames whose slow id is a semantic token (generate_blocking,
             # lm/generate.py:196-207); streaming requests decode every frame (__init__.py:88-92)
-            tc = self.tts.token_config
-            sel = [f for f in range(r.emitted, n) if r.stream or tc.semantic_start_id <= codes[slot, f, 0] <= tc.semantic_end_id]
+            slow = codes[slot, r.emitted:n, 0]
+            keep = np.ones(n - r.emitted, bool) if r.stream else (slow >= tc.semantic_start_id) & (slow <= tc.semantic_end_id)
+            cols = codes[slot, r.emitted:n][keep][:, -nq:].astype(np.int32)
+            finished = (bool(done[slot]) and int(n_frames[slot]) > 0) or n >= r.max_new_tokens + 1
             r.emitted = n
-            finished = bool(done[slot]) or r.emitted >= r.max_new_tokens + 1
-            if sel:
-                cols = codes[slot, sel][:, -nq:].astype(np.int32)
+            if cols.shape[0]:
                 if r.stream:
-                    self._decode_frames(r, cols)
+                    self._queue_codec([r], [cols], r.msess, last=[finished])
                 else:
                     r.pending.append(cols)
             if finished:
                 del self._active[slot]
                 self._free.append(slot)
                 if r.stream:
-                    self._release_codec(r.msess)
+                    if not cols.shape[0]:
+                        self._deliveries.append((None, None, [(r, 0, 0, True)]))
+                    self._codec_pool.setdefault(r.msess.chunk, []).append(r.msess)
                     r.msess = None
-                    r.out.put(None)
                 else:
                     self._finished.append(r)
 
-    CODEC_BATCH, CODEC_CHUNK = 8, 64
+    # ------------------------------------------------------------------ worker: codec passes and delivery
+    def _queue_codec(self, reqs, cols_list, sess, last) -> None:
+        """Queue the codec over the given utterances (one slot each, padded to the longest) on the compute stream; the PCM
+        is fetched by _deliver once the event behind the pass has fired."""
+        torch = self._torch
+        nq = cols_list[0].shape[1]
+        F = max(c.shape[0] for c in cols_list)
+        grid = np.zeros((len(reqs), F, nq), np.int32)
+        for b, c in enumerate(cols_list):
+            grid[b, : c.shape[0]] = c
+        codes = torch.from_numpy(grid).cuda()
+        pcm = torch.empty(len(reqs), F * 1920, dtype=torch.float32, device="cuda")
+        for f0 in range(0, F, sess.chunk):
+            sess.decode_chunk(codes, f0, min(sess.chunk, F - f0), pcm, code_offset=0)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._deliveries.append((ev, pcm, [(r, b, c.shape[0] * 1920, fin) for b, (r, c, fin) in enumerate(zip(reqs, cols_list, last))]))
 
     def _decode_finished(self, force: bool) -> None:
-        """Codec pass over up to CODEC_BATCH complete blocking utterances at once (each in its own slot from position 0,
-        the shorter ones padded at the end: the decoder is causal, so the padding cannot reach their samples).  Runs when
-        enough utterances wait, when they have waited two ticks, or when nothing else is going on."""
+        """Codec pass over up to CODEC_BATCH complete blocking utterances (each in its own slot from position 0, the shorter
+        ones padded at the end: the decoder is causal, so the padding cannot reach their samples).  Queued when enough
+        utterances wait, when they have waited two ticks, or when nothing else is going on."""
         if not self._finished:
             return
         self._finished_age += 1
         if not (force or len(self._finished) >= self.CODEC_BATCH or self._finished_age >= 2):
             return
-        torch = self._torch
         from ..engine import MimiSession
 
         if self._batch_codec is None:
@@ -202,36 +239,65 @@ class BatchScheduler:
         while self._finished:
             batch, self._finished = self._finished[: self.CODEC_BATCH], self._finished[self.CODEC_BATCH:]
             cols = [np.concatenate(r.pending) if r.pending else np.zeros((0, nq), np.int32) for r in batch]
-            F = max(c.shape[0] for c in cols)
-            if F > 0:
-                grid = np.zeros((len(batch), F, nq), np.int32)
-                for b, c in enumerate(cols):
-                    grid[b, : c.shape[0]] = c
-                pcm = self._batch_codec.decode(torch.from_numpy(grid).cuda()).cpu().numpy()
-                for b, (r, c) in enumerate(zip(batch, cols)):
-                    if c.shape[0]:
-                        r.out.put(pcm[b, : c.shape[0] * 1920].copy())
             for r in batch:
                 r.pending = []
-                r.out.put(None)
+            if max(c.shape[0] for c in cols) == 0:
+                self._deliveries.append((None, None, [(r, 0, 0, True) for r in batch]))
+                continue
+            self._batch_codec.reset()
+            self._queue_codec(batch, cols, self._batch_codec, last=[True] * len(batch))
         self._finished_age = 0
 
+    def _deliver(self, wait: bool) -> None:
+        """Hand finished codec passes to their requests, in order; ``wait``: block on the oldest one."""
+        torch = self._torch
+        while self._deliveries:
+            ev, pcm, items = self._deliveries[0]
+            if ev is not None:
+                if not (wait or ev.query()):
+                    return
+                with torch.cuda.stream(self._copy_stream):
+                    self._copy_stream.wait_event(ev)
+                    host = pcm.to("cpu", non_blocking=True)
+                self._copy_stream.synchronize()
+                host = host.numpy()
+            self._deliveries.pop(0)
+            for r, b, n, fin in items:
+                if n:
+                    r.out.put(host[b, :n].copy())
+                if fin:
+                    r.out.put(None)
+            wait = False
+
+    # ------------------------------------------------------------------ worker: main loop
     def _run(self) -> None:
+        torch = self._torch
         try:
-            while not self._stop.is_set():
-                self._admit()
-                if not self._active:
-                    try:
-                        self._pending.put(self._pending.get(timeout=0.05))  # idle: wait for work without spinning
-                    except queue.Empty:
-                        pass
-                    continue
-                self._drain()           # frame 0 of freshly admitted requests / last tick's frames
-                if self._active:
-                    self.session.decode(self.tick)  # asynchronous: the codec pass below queues behind it
-                self._decode_finished(force=not self._active)
+            compute = torch.cuda.Stream()
+            self._copy_stream = torch.cuda.Stream()
+            with torch.cuda.stream(compute):
+                while not self._stop.is_set():
+                    self._admit()
+                    if not self._active:
+                        self._consume_snapshots(keep=0)
+                        self._decode_finished(force=True)
+                        if self._deliveries:
+                            self._deliver(wait=True)
+                            continue
+                        try:
+                            self._pending.put(self._pending.get(timeout=0.05))  # idle: wait for work without spinning
+                        except queue.Empty:
+                            pass
+                        continue
+                    self._tick_and_snapshot()          # tick k and its snapshot are queued ...
+                    self._decode_finished(force=False)
+                    self._deliver(wait=False)
+                    self._consume_snapshots(keep=1)    # ... while the host looks at what tick k-1 produced
         except Exception as e:  # engine failure: fail every waiter loudly
             for r in list(self._active.values()) + self._finished:
                 r.out.put(e)
+            for _, _, items in self._deliveries:
+                for r, _, _, _ in items:
+                    r.out.put(e)
             while not self._pending.empty():
                 self._pending.get_nowait().out.put(e)

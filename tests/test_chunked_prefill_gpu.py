@@ -90,3 +90,30 @@ def test_decode_runs_between_chunks_of_other_slots():
         assert np.array_equal(codes[slot, : n[slot]].T, want), f"slot {slot}"
     assert np.array_equal(first_life_of_1.T, logs[1].as_tensor().numpy()[:, : first_life_of_1.shape[0]])
     s.close(); eng.close()
+
+
+@pytest.mark.parametrize("chunk", [None, 40])
+def test_deferred_frame0_gives_the_same_ids(chunk):
+    """smoltts_lm_prefill_deferred: KV fill only, frame 0 from the next decode frame — same ids as prefill + decode, also
+    when other slots are in the middle of their utterances."""
+    from smoltts_amd.engine import LMSession
+
+    cfg, eng, orc, pe = _setup("tiny", 17)
+    P = _prompts(pe, [30, 5, 120, 77], seed=4)
+    frames = 20
+    s = LMSession(eng, max_batch=4, max_seq=300, max_rows=400, max_frames=frames)
+    s.prefill(P[:2], slots=[0, 1], stop_on_eos=False)          # slots 0, 1: ordinary start (frame 0 now)
+    s.decode(5)
+    if chunk:
+        s.prefill_chunked(P[2:], slots=[2, 3], stop_on_eos=False, chunk=chunk, defer_frame0=True)
+    else:
+        s.prefill(P[2:], slots=[2, 3], stop_on_eos=False, defer_frame0=True)
+    codes, n, done, _ = s.fetch()
+    assert n.tolist() == [6, 6, 0, 0] and done.tolist()[2:] == [0, 0]
+    s.decode(7)
+    codes, n, done, _ = s.fetch()
+    assert n.tolist() == [13, 13, 7, 7]
+    logs = orc.generate([torch.from_numpy(p) for p in P], max_frames=frames, stop_on_eos=False)
+    for slot in range(4):
+        assert np.array_equal(codes[slot, : n[slot]].T, logs[slot].as_tensor().numpy()[:, : n[slot]]), f"slot {slot}"
+    s.close(); eng.close()
