@@ -226,6 +226,10 @@ void smoltts_mimi_session_destroy(SmolttsMimiSession* s);
 /* Forget all streaming state of the session (start new utterances in every slot). */
 int smoltts_mimi_reset(SmolttsMimiSession* s, void* stream);
 
+/* Forget the streaming state of the listed slots only (slots_host: host memory): the other slots' streams continue.
+ * Every slot keeps its own transformer position, so streams of different utterances can share one session. */
+int smoltts_mimi_reset_slots(SmolttsMimiSession* s, const int32_t* slots_host, int32_t n_slots, void* stream);
+
 /* Decode n_frames new frames for slots [0, batch): codes_dev int32 [batch][codes_stride] where
  * frame f of slot b starts at codes_dev[b*codes_stride + f*frame_stride + code_offset] and holds
  * num_codebooks ints; pcm_dev float [batch][pcm_stride] receives 1920*n_frames samples per slot.

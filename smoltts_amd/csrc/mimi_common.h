@@ -20,8 +20,9 @@ int run_mimi_transformer(const char* arena, const SmolttsMimiLayerWeights* layer
                          int cache_len, int window, const MimiTransformerBufs& b, int rows, int rows_per_slot,
                          float* last_out, int64_t last_bstride, hipStream_t st);
 
-// row_slot[m] = m / rows_per_slot, row_pos[m] = pos0 + m % rows_per_slot
-int launch_mimi_rows(int n_rows, int rows_per_slot, int pos0, int* row_pos, int* row_slot, hipStream_t st);
+// row_slot[m] = m / rows_per_slot, row_pos[m] = (slot_pos ? slot_pos[slot] : pos0) + m % rows_per_slot
+int launch_mimi_rows(int n_rows, int rows_per_slot, int pos0, int* row_pos, int* row_slot, hipStream_t st,
+                     const int* slot_pos = nullptr);
 
 inline SmolttsGemmArgs mimi_gemm_f32(const void* w, const float* x, long ldx, int M, int N, int K) {
   SmolttsGemmArgs a;

@@ -12,6 +12,7 @@
 // F frames in chunks == decoding them at once == MimiModel.decode.  (The reference's own
 // decode_step re-runs the upsample statelessly, mimi.py:77, and therefore differs from its batch
 // decode; this engine carries the upsample tap overlap instead.)
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -52,7 +53,9 @@ struct SmolttsMimiSession {
   size_t halo_total;         // bytes of everything that reset must zero: tracked via pointers below
   char* zero_begin;
   size_t zero_bytes;
-  int positions;     // transformer positions consumed so far (uniform over slots)
+  int* pos_dev;      // [B] transformer positions consumed so far, per slot (slots are reset independently when streams
+                     // of different utterances share the session)
+  int* pos_host;     // host mirror (deterministic: += 2 * frames per call for the slots decoded, 0 on reset)
   int parity;
 };
 
@@ -79,6 +82,7 @@ void carve(SmolttsMimiSession* s, char* base, size_t* total) {
   const size_t z0 = cv.off;
   s->carry[0] = cv.take<float>(B * D);
   s->carry[1] = cv.take<float>(B * D);
+  s->pos_dev = cv.take<int>(B);
   for (int i = 0; i < NBUF; ++i) {
     s->buf_bstride[i] = (size_t)(BUF_HALO[i] + BUF_RPF[i] * F) * BUF_C[i];
     s->buf[i] = cv.take<float>(B * s->buf_bstride[i]);
@@ -134,12 +138,17 @@ __global__ __launch_bounds__(128) void rvq_upsample_kernel(const int* codes, lon
   if (f == n_frames - 1) *reinterpret_cast<float4*>(carry_out + (long)b * D + c) = cur;
 }
 
-__global__ void mimi_rows_kernel(int n_rows, int rows_per_slot, int pos0, int* row_pos, int* row_slot) {
+__global__ void mimi_rows_kernel(int n_rows, int rows_per_slot, int pos0, const int* slot_pos, int* row_pos, int* row_slot) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= n_rows) return;
   const int b = m / rows_per_slot;
   row_slot[m] = b;
-  row_pos[m] = pos0 + (m - b * rows_per_slot);
+  row_pos[m] = (slot_pos ? slot_pos[b] : pos0) + (m - b * rows_per_slot);
+}
+
+__global__ void mimi_advance_kernel(int batch, int by, int* slot_pos) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < batch) slot_pos[b] += by;
 }
 
 // Shift the last `halo` rows of every conv input buffer to its front (streaming carry).
@@ -164,8 +173,8 @@ __global__ __launch_bounds__(256) void halo_shift_kernel(HaloDesc d) {
 
 namespace smoltts {
 
-int launch_mimi_rows(int n_rows, int rows_per_slot, int pos0, int* row_pos, int* row_slot, hipStream_t st) {
-  hipLaunchKernelGGL(mimi_rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, st, n_rows, rows_per_slot, pos0, row_pos, row_slot);
+int launch_mimi_rows(int n_rows, int rows_per_slot, int pos0, int* row_pos, int* row_slot, hipStream_t st, const int* slot_pos) {
+  hipLaunchKernelGGL(mimi_rows_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, st, n_rows, rows_per_slot, pos0, slot_pos, row_pos, row_slot);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
 }
@@ -267,22 +276,45 @@ int smoltts_mimi_session_create(SmolttsMimi* m, void* slab_dev, size_t slab_byte
   s->m = m; s->B = max_batch; s->chunk = max_chunk_frames;
   size_t total = 0;
   carve(s, (char*)slab_dev, &total);
-  if (hipMemset(s->zero_begin, 0, s->zero_bytes) != hipSuccess) {
+  s->pos_host = static_cast<int*>(calloc((size_t)max_batch, sizeof(int)));
+  if (s->pos_host == nullptr || hipMemset(s->zero_begin, 0, s->zero_bytes) != hipSuccess) {
+    free(s->pos_host);
     delete s;
-    set_error("mimi_session_create: hipMemset failed");
+    set_error("mimi_session_create: allocation or hipMemset failed");
     return SMOLTTS_E_HIP;
   }
   *out = s;
   return SMOLTTS_OK;
 }
 
-void smoltts_mimi_session_destroy(SmolttsMimiSession* s) { delete s; }
+void smoltts_mimi_session_destroy(SmolttsMimiSession* s) {
+  if (!s) return;
+  free(s->pos_host);
+  delete s;
+}
 
 int smoltts_mimi_reset(SmolttsMimiSession* s, void* stream) {
   ST_REQUIRE(s, SMOLTTS_E_INVALID, "mimi_reset: null session");
   ST_CHECK_HIP(hipMemsetAsync(s->zero_begin, 0, s->zero_bytes, (hipStream_t)stream));
-  s->positions = 0;
+  for (int b = 0; b < s->B; ++b) s->pos_host[b] = 0;
   s->parity = 0;
+  return SMOLTTS_OK;
+}
+
+int smoltts_mimi_reset_slots(SmolttsMimiSession* s, const int32_t* slots_host, int32_t n_slots, void* stream) {
+  ST_REQUIRE(s && slots_host && n_slots > 0, SMOLTTS_E_INVALID, "mimi_reset_slots: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < n_slots; ++i) {
+    const int b = slots_host[i];
+    ST_REQUIRE(b >= 0 && b < s->B, SMOLTTS_E_INVALID, "mimi_reset_slots: slot %d out of range", b);
+    ST_CHECK_HIP(hipMemsetAsync(s->carry[0] + (size_t)b * D, 0, D * sizeof(float), st));
+    ST_CHECK_HIP(hipMemsetAsync(s->carry[1] + (size_t)b * D, 0, D * sizeof(float), st));
+    ST_CHECK_HIP(hipMemsetAsync(s->pos_dev + b, 0, sizeof(int), st));
+    for (int j = 0; j < NBUF; ++j)  // only the halo rows carry state from chunk to chunk
+      if (BUF_HALO[j] > 0)
+        ST_CHECK_HIP(hipMemsetAsync(s->buf[j] + (size_t)b * s->buf_bstride[j], 0, (size_t)BUF_HALO[j] * BUF_C[j] * sizeof(float), st));
+    s->pos_host[b] = 0;
+  }
   return SMOLTTS_OK;
 }
 
@@ -316,8 +348,9 @@ static int decode_chunk_impl(SmolttsMimiSession* s, const int32_t* codes_dev, in
              "mimi_decode_chunk: batch=%d frames=%d exceed the session (%d, %d)", batch, n_frames, s->B, s->chunk);
   const SmolttsMimi* m = s->m;
   const SmolttsMimiConfig& c = m->cfg;
-  ST_REQUIRE(s->positions + 2 * n_frames <= c.max_positions, SMOLTTS_E_CAPACITY,
-             "mimi_decode_chunk: %d positions exceed max_positions=%d", s->positions + 2 * n_frames, c.max_positions);
+  for (int b = 0; b < batch; ++b)
+    ST_REQUIRE(s->pos_host[b] + 2 * n_frames <= c.max_positions, SMOLTTS_E_CAPACITY,
+               "mimi_decode_chunk: slot %d: %d positions exceed max_positions=%d", b, s->pos_host[b] + 2 * n_frames, c.max_positions);
   ST_REQUIRE(frame_stride >= c.num_codebooks + code_offset && code_offset >= 0 && pcm_stride >= (int64_t)SAMPLES * n_frames &&
                  pcm_stride % 4 == 0 && ((uintptr_t)pcm_dev & 15) == 0,
              SMOLTTS_E_INVALID, "mimi_decode_chunk: bad strides");
@@ -330,7 +363,7 @@ static int decode_chunk_impl(SmolttsMimiSession* s, const int32_t* codes_dev, in
                      c.num_codebooks, F, (const float*)(A + m->w.rvq_table), (const float*)(A + m->w.upsample_w),
                      s->carry[s->parity], s->carry[s->parity ^ 1], s->tx);
   ST_CHECK_HIP(hipGetLastError());
-  ST_TRY(launch_mimi_rows(R, Tt, s->positions, s->row_pos, s->row_slot, st));
+  ST_TRY(launch_mimi_rows(R, Tt, 0, s->row_pos, s->row_slot, st, s->pos_dev));
 
   // 2. decoder transformer (transformer.py:109-131); the last layer writes straight into conv0's input
   //    buffer, behind its halo
@@ -386,7 +419,9 @@ static int decode_chunk_impl(SmolttsMimiSession* s, const int32_t* codes_dev, in
     hipLaunchKernelGGL(halo_shift_kernel, dim3(batch, NBUF), dim3(256), 6 * 512 * sizeof(float), st, d);
     ST_CHECK_HIP(hipGetLastError());
   }
-  s->positions += Tt;
+  hipLaunchKernelGGL(mimi_advance_kernel, dim3((batch + 63) / 64), dim3(64), 0, st, batch, Tt, s->pos_dev);
+  ST_CHECK_HIP(hipGetLastError());
+  for (int b = 0; b < batch; ++b) s->pos_host[b] += Tt;
   s->parity ^= 1;
   return SMOLTTS_OK;
 }

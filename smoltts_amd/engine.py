@@ -98,7 +98,7 @@ _EXPORTS = [
     "smoltts_mimi_decode_chunk", "smoltts_k_gemm", "smoltts_k_attention", "smoltts_k_embed", "smoltts_k_argmax",
     "smoltts_k_layernorm", "smoltts_profile_begin", "smoltts_profile_end", "smoltts_k_gemm3", "smoltts_k_x3_pack",
     "smoltts_debug_duplicate", "smoltts_session_drop_graph", "smoltts_session_set_sampling", "smoltts_k_sample",
-    "smoltts_lm_prefill_chunk", "smoltts_lm_prefill_deferred", "smoltts_mimi_encoder_create", "smoltts_mimi_encoder_destroy", "smoltts_mimi_encode_frames",
+    "smoltts_lm_prefill_chunk", "smoltts_lm_prefill_deferred", "smoltts_mimi_reset_slots", "smoltts_mimi_encoder_create", "smoltts_mimi_encoder_destroy", "smoltts_mimi_encode_frames",
     "smoltts_mimi_encode_workspace_bytes", "smoltts_mimi_encode",
 ]
 
@@ -150,6 +150,7 @@ def load_library(path: Optional[Path] = None):
                                      C.c_int32, C.c_void_p, C.c_void_p]
     lib.smoltts_debug_duplicate.argtypes = [C.c_int32, C.c_int32]
     lib.smoltts_session_drop_graph.argtypes = [C.c_void_p]
+    lib.smoltts_mimi_reset_slots.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.smoltts_lm_prefill_deferred.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                                 C.c_int32, C.c_void_p]
     lib.smoltts_lm_prefill_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
@@ -526,6 +527,11 @@ class MimiSession:
 
     def reset(self) -> None:
         check(self.lib.smoltts_mimi_reset(self.handle, current_stream_ptr()), "smoltts_mimi_reset")
+
+    def reset_slots(self, slots: Sequence[int]) -> None:
+        """Start new streams in the listed slots; the other slots' streams continue."""
+        arr = (C.c_int32 * len(slots))(*slots)
+        check(self.lib.smoltts_mimi_reset_slots(self.handle, arr, len(slots), current_stream_ptr()), "smoltts_mimi_reset_slots")
 
     def decode_chunk(self, codes: torch.Tensor, f0: int, n_frames: int, pcm: torch.Tensor, code_offset: int = 0) -> None:
         """codes: device int32 [batch, F, row] (row >= code_offset + num_codebooks); decodes frames

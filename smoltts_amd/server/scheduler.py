@@ -12,8 +12,9 @@ The loop is pipelined so that the GPU never waits for Python: tick k is queued, 
 is queued behind it, and *then* the host reads the snapshot of tick k-1 (on a copy stream) and does its bookkeeping while
 tick k runs.  A slot that finished in tick k-1 is therefore refilled in tick k+1 (one tick of that slot is the price).
 Codec work is queued on the same stream behind the ticks and its PCM is fetched on the copy stream when its event has
-fired: a streaming request owns a one-slot codec session and is decoded every tick; a blocking request is decoded when its
-utterance is complete, up to ``CODEC_BATCH`` finished utterances per codec pass.  A request's PCM is identical to what
+fired: streaming requests share one codec session whose slots mirror the LM slots (every slot keeps its own stream
+position, ``smoltts_mimi_reset_slots`` starts a new stream in a slot) and are decoded together, one codec pass per tick; a
+blocking request is decoded when its utterance is complete, up to ``CODEC_BATCH`` finished utterances per codec pass.  A request's PCM is identical to what
 ``SmolTTS.__call__`` / ``stream`` return for it alone.
 """
 from __future__ import annotations
@@ -70,6 +71,8 @@ class BatchScheduler:
         self._finished: List[_Request] = []     # complete blocking utterances waiting for their (batched) codec pass
         self._finished_age = 0
         self._batch_codec = None                # one multi-slot codec session for those passes
+        self._stream_codec = None               # codec session whose slot b carries the stream of LM slot b (streaming requests)
+        self._codec_age = [0] * max_batch       # codec passes each of its slots has seen since that slot's last reset
         self._deliveries: List[tuple] = []      # (event, pcm on the device, [(request, first sample, n samples, last?)]) in order
         self._snaps: List[tuple] = []           # snapshots of the output ring the host has not looked at yet (oldest first)
         self._tick_no = 0                       # ticks queued so far
@@ -102,9 +105,10 @@ class BatchScheduler:
             for sess in pool:
                 sess.close()
         self._codec_pool.clear()
-        if self._batch_codec is not None:
-            self._batch_codec.close()
-            self._batch_codec = None
+        for name in ("_batch_codec", "_stream_codec"):
+            if getattr(self, name) is not None:
+                getattr(self, name).close()
+                setattr(self, name, None)
         self.session.close()
 
     # ------------------------------------------------------------------ worker: admission
@@ -135,8 +139,17 @@ class BatchScheduler:
         else:
             # frame 0 of the new slots comes out of the next tick's first frame (no separate tail for all slots)
             self.session.prefill([r.prompt for r in new], slots=[r.slot for r in new], stop_on_eos=True, defer_frame0=True)
+        streams = [r.slot for r in new if r.stream]
+        if streams:
+            from ..engine import MimiSession
+
+            if self._stream_codec is None:
+                self._stream_codec = MimiSession(self.tts.codec, max_batch=self.B, max_chunk_frames=max(self.tick, 1))
+                self._stream_codec.reset()
+            self._stream_codec.reset_slots(streams)
+            for b in streams:
+                self._codec_age[b] = 0
         for r in new:
-            r.msess = self._codec_session(max(self.tick, 1) + 1) if r.stream else None
             r.first_tick = self._tick_no
             self._active[r.slot] = r
 
@@ -155,7 +168,31 @@ class BatchScheduler:
         torch = self._torch
         self.session.decode(self.tick)
         s = self.session
-        snap = (s.codes.clone(), s.n_frames.clone(), s.done.clone(), torch.cuda.Event(), self._tick_no)
+        pcm = None
+        streaming = [r for r in self._active.values() if r.stream]
+        if streaming:
+            # the frames this tick gives slot b sit at ring positions [f0_b, f0_b + tick): f0_b follows from the tick count
+            # alone while the request is alive (frames of a slot that has stopped are garbage here and never delivered)
+            f0 = np.zeros(self.B, np.int64)
+            for r in streaming:
+                f0[r.slot] = (self._tick_no - r.first_tick) * self.tick
+            # the pass runs over all slots; those without a stream (blocking requests, idle) decode garbage that nobody
+            # reads, but their stream position advances too: restart them before it would reach the codec's capacity
+            live = {r.slot for r in streaming}
+            cap = int(self.tts.codec.c_cfg.max_positions)
+            stale = [b for b in range(self.B) if b not in live and (self._codec_age[b] + 2) * 2 * self.tick > cap]
+            if stale:
+                self._stream_codec.reset_slots(stale)
+                for b in stale:
+                    self._codec_age[b] = 0
+            for b in range(self.B):
+                self._codec_age[b] += 1
+            idx = (torch.from_numpy(f0).cuda()[:, None] + torch.arange(self.tick, device="cuda")[None]).clamp_(max=self.max_frames - 1)
+            nq = self.tts.config.num_codebooks
+            chunk = s.codes[torch.arange(self.B, device="cuda")[:, None], idx][:, :, -nq:].contiguous()
+            pcm = torch.empty(self.B, self.tick * 1920, dtype=torch.float32, device="cuda")
+            self._stream_codec.decode_chunk(chunk, 0, self.tick, pcm, code_offset=0)
+        snap = (s.codes.clone(), s.n_frames.clone(), s.done.clone(), torch.cuda.Event(), self._tick_no, pcm)
         snap[3].record(torch.cuda.current_stream())
         self._snaps.append(snap)
         self._tick_no += 1
@@ -165,44 +202,48 @@ class BatchScheduler:
         only just been queued; its predecessor finished before that tick could start)."""
         torch = self._torch
         while len(self._snaps) > keep:
-            codes_d, n_d, done_d, ev, tick_no = self._snaps.pop(0)
+            codes_d, n_d, done_d, ev, tick_no, pcm_d = self._snaps.pop(0)
             with torch.cuda.stream(self._copy_stream):
                 self._copy_stream.wait_event(ev)
                 codes = codes_d.to("cpu", non_blocking=True)
                 n_frames = n_d.to("cpu", non_blocking=True)
                 done = done_d.to("cpu", non_blocking=True)
+                pcm = pcm_d.to("cpu", non_blocking=True) if pcm_d is not None else None
             self._copy_stream.synchronize()
-            self._drain(codes.numpy(), n_frames.numpy(), done.numpy(), tick_no)
+            self._drain(codes.numpy(), n_frames.numpy(), done.numpy(), tick_no, None if pcm is None else pcm.numpy())
 
-    def _drain(self, codes, n_frames, done, tick_no: int) -> None:
+    def _drain(self, codes, n_frames, done, tick_no: int, pcm) -> None:
         nq = self.tts.config.num_codebooks
         tc = self.tts.token_config
         for slot, r in list(self._active.items()):
             if tick_no < r.first_tick:  # the snapshot predates this request: it shows the slot's previous tenant
                 continue
             n = min(int(n_frames[slot]), r.max_new_tokens + 1)
-            # blocking requests keep only frames whose slow id is a semantic token (generate_blocking,
-            # lm/generate.py:196-207); streaming requests decode every frame (__init__.py:88-92)
-            slow = codes[slot, r.emitted:n, 0]
-            keep = np.ones(n - r.emitted, bool) if r.stream else (slow >= tc.semantic_start_id) & (slow <= tc.semantic_end_id)
-            cols = codes[slot, r.emitted:n][keep][:, -nq:].astype(np.int32)
             finished = (bool(done[slot]) and int(n_frames[slot]) > 0) or n >= r.max_new_tokens + 1
+            if r.stream:
+                # streaming requests decode every frame (__init__.py:88-92); this tick's PCM of the slot starts at its frame
+                # r.emitted (== f0 of the tick: one codec frame per LM frame)
+                k = n - r.emitted
+                if k > 0:
+                    assert pcm is not None and r.emitted == (tick_no - r.first_tick) * self.tick, "stream bookkeeping out of step"
+                    r.out.put(pcm[slot, : k * 1920].copy())
+                r.emitted = n
+                if finished:
+                    del self._active[slot]
+                    self._free.append(slot)
+                    r.out.put(None)
+                continue
+            # blocking requests keep only frames whose slow id is a semantic token (generate_blocking, lm/generate.py:196-207)
+            slow = codes[slot, r.emitted:n, 0]
+            keep = (slow >= tc.semantic_start_id) & (slow <= tc.semantic_end_id)
+            cols = codes[slot, r.emitted:n][keep][:, -nq:].astype(np.int32)
             r.emitted = n
             if cols.shape[0]:
-                if r.stream:
-                    self._queue_codec([r], [cols], r.msess, last=[finished])
-                else:
-                    r.pending.append(cols)
+                r.pending.append(cols)
             if finished:
                 del self._active[slot]
                 self._free.append(slot)
-                if r.stream:
-                    if not cols.shape[0]:
-                        self._deliveries.append((None, None, [(r, 0, 0, True)]))
-                    self._codec_pool.setdefault(r.msess.chunk, []).append(r.msess)
-                    r.msess = None
-                else:
-                    self._finished.append(r)
+                self._finished.append(r)
 
     # ------------------------------------------------------------------ worker: codec passes and delivery
     def _queue_codec(self, reqs, cols_list, sess, last) -> None:
@@ -292,7 +333,10 @@ class BatchScheduler:
                     self._tick_and_snapshot()          # tick k and its snapshot are queued ...
                     self._decode_finished(force=False)
                     self._deliver(wait=False)
-                    self._consume_snapshots(keep=1)    # ... while the host looks at what tick k-1 produced
+                    # ... while the host looks at what tick k-1 produced; unless a stream is still waiting for its first
+                    # chunk: then this tick is read as soon as it is done (first-audio latency before pipelining)
+                    first_chunk_due = any(r.stream and r.emitted == 0 for r in self._active.values())
+                    self._consume_snapshots(keep=0 if first_chunk_due else 1)
         except Exception as e:  # engine failure: fail every waiter loudly
             for r in list(self._active.values()) + self._finished:
                 r.out.put(e)

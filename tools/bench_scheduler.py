@@ -16,6 +16,7 @@ from smoltts_amd.synthetic import named_config, synthetic_lm_state  # noqa: E402
 
 n_req = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 tick = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+streaming = len(sys.argv) > 3 and sys.argv[3] == "stream"
 cfg = named_config("smoltts_byte_150m")
 tts = SmolTTS(state=synthetic_lm_state(cfg, seed=0), config=cfg, mimi_state=synthetic_mimi_state(seed=0))
 rng = np.random.default_rng(1)
@@ -24,11 +25,25 @@ rng2 = np.random.default_rng(2)
 texts = ["".join(chr(int(c)) for c in rng2.integers(32, 127, size=int(rng2.integers(40, 161)))) for _ in range(n_req)]
 sched = BatchScheduler(tts, max_batch=32, frames_per_tick=tick, generation_settings=GenerationSettings.greedy(max_new_tokens=400))
 sched.synthesize("warm up", max_new_tokens=8)
+if streaming:
+    list(sched.iter_chunks(sched.submit("warm up the stream path", "heart", stream=True, max_new_tokens=8)))
 samples = [0] * n_req
 
 
+first_chunk_ms = []
+
+
 def worker(i):
-    samples[i] = sched.synthesize(texts[i], "heart", max_new_tokens=int(budgets[i])).shape[0]
+    if streaming:
+        t1 = time.perf_counter()
+        n = 0
+        for j, chunk in enumerate(sched.iter_chunks(sched.submit(texts[i], "heart", stream=True, max_new_tokens=int(budgets[i])))):
+            if j == 0:
+                first_chunk_ms.append((time.perf_counter() - t1) * 1e3)
+            n += chunk.shape[0]
+        samples[i] = n
+    else:
+        samples[i] = sched.synthesize(texts[i], "heart", max_new_tokens=int(budgets[i])).shape[0]
 
 
 t0 = time.perf_counter()
@@ -39,5 +54,7 @@ for t in threads:
     t.join()
 dt = time.perf_counter() - t0
 frames = sum(samples) // 1920
-print(f"{n_req} requests, {frames} frames of audio in {dt:.2f} s -> {frames / dt:.0f} frames/s ({frames / dt / 12.5:.0f}x real time), tick {tick}")
+print(f"{n_req} {'streaming' if streaming else 'blocking'} requests, {frames} frames of audio in {dt:.2f} s -> {frames / dt:.0f} frames/s "
+      f"({frames / dt / 12.5:.0f}x real time), tick {tick}"
+      + (f"; time to first chunk p50 {np.median(first_chunk_ms):.1f} ms (includes queueing for a slot)" if first_chunk_ms else ""))
 sched.close()
