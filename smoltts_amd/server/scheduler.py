@@ -36,7 +36,6 @@ class _Request:
     out: "queue.Queue" = field(default_factory=queue.Queue)  # np.ndarray chunks, then None (or an Exception)
     slot: int = -1
     emitted: int = 0
-    msess: object = None
     pending: list = field(default_factory=list)  # blocking requests: audio-code columns awaiting their codec pass
     prompt: object = None
     first_tick: int = 0  # index of the tick that produces this request's frame 0: older snapshots show the slot's previous tenant
@@ -67,7 +66,6 @@ class BatchScheduler:
         self._active: Dict[int, _Request] = {}
         self._free: List[int] = list(range(max_batch))
         self._stop = threading.Event()
-        self._codec_pool: Dict[int, list] = {}  # chunk size -> idle one-slot codec sessions (their slabs are re-used)
         self._finished: List[_Request] = []     # complete blocking utterances waiting for their (batched) codec pass
         self._finished_age = 0
         self._batch_codec = None                # one multi-slot codec session for those passes
@@ -101,10 +99,6 @@ class BatchScheduler:
     def close(self) -> None:
         self._stop.set()
         self._thread.join(timeout=30)
-        for pool in self._codec_pool.values():
-            for sess in pool:
-                sess.close()
-        self._codec_pool.clear()
         for name in ("_batch_codec", "_stream_codec"):
             if getattr(self, name) is not None:
                 getattr(self, name).close()
@@ -152,14 +146,6 @@ class BatchScheduler:
         for r in new:
             r.first_tick = self._tick_no
             self._active[r.slot] = r
-
-    def _codec_session(self, chunk: int):
-        from ..engine import MimiSession
-
-        pool = self._codec_pool.setdefault(chunk, [])
-        sess = pool.pop() if pool else MimiSession(self.tts.codec, max_batch=1, max_chunk_frames=chunk)
-        sess.reset()
-        return sess
 
     # ------------------------------------------------------------------ worker: ticks and snapshots
     def _tick_and_snapshot(self) -> None:
