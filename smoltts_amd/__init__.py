@@ -43,7 +43,7 @@ class SmolTTS:
         self.token_config = TokenConfig.from_tokenizer(tokenizer, config)
         self.lm = LMEngine(config, state, self.token_config, numerics or NumericsMode.torch_reference())
         self.prompt_encoder = PromptEncoder.from_config(tokenizer, config, self.token_config)
-        self.codec = MimiEngine(mimi_state, num_codebooks=config.num_codebooks, window=codec_window, max_positions=2 * 1026 + 2)
+        self.codec = MimiEngine(mimi_state, num_codebooks=config.num_codebooks, window=codec_window, max_positions=2 * (1026 + 64))  # 1025 frames + a scheduler tick of overshoot, 2 positions per frame
         # the encode half (voice-clone prompts) is packed on first use, and only if the checkpoint carries it
         self._mimi_encoder_state = mimi_state if "encoder.layers.0.conv.weight" in mimi_state else None
         self._codec_window = codec_window
