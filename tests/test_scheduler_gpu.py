@@ -48,3 +48,51 @@ def test_scheduler_matches_single_request_results():
         sched2.synthesize("x" * 600)
     assert sched2.synthesize("still alive").shape[0] % 1920 == 0
     sched2.close()
+
+
+def test_scheduler_stops_on_eos_like_the_facade():
+    """<|im_end|> ends an utterance inside a tick: the stream delivers the frames up to and including the terminating one,
+    the blocking answer drops it (non-semantic slow id), the slot is re-used, and everything equals the single-request façade."""
+    import dataclasses
+
+    from smoltts_amd import SmolTTS
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+    from smoltts_amd.config import GenerationSettings
+    from smoltts_amd.engine import LMEngine
+    from smoltts_amd.generate import generate_blocking
+    from smoltts_amd.server.scheduler import BatchScheduler
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+
+    cfg = named_config("tiny")
+    state = synthetic_lm_state(cfg, seed=21)
+    tts = SmolTTS(state=state, config=cfg, mimi_state=synthetic_mimi_state(seed=5))
+    gs = GenerationSettings.greedy(max_new_tokens=40)
+    texts = ["first request", "second, longer request text", "3", "the fourth one"]
+    # pick as <|im_end|> the slow id that the first utterance emits at frame 5 (synthetic weights never say 270 by themselves)
+    grid = generate_blocking(tts.lm, tts._get_prompt(texts[0], "heart"), gs, audio_only=False)
+    eos = int(grid[0, 0, 5])
+    tts.token_config = dataclasses.replace(tts.token_config, im_end_id=eos)
+    tts.lm = LMEngine(cfg, state, tts.token_config, tts.lm.numerics)
+    want_stream = [np.concatenate(list(tts.stream(t, "heart", generation_settings=gs))) for t in texts]
+    want_block = [tts(t, "heart", generation_settings=gs) for t in texts]
+    assert want_stream[0].shape[0] <= 6 * 1920  # the first utterance really stops at (or before) its frame 5
+    sched = BatchScheduler(tts, max_batch=2, frames_per_tick=4, generation_settings=gs)
+    got_s, got_b = [None] * 4, [None] * 4
+
+    def worker(i, stream):
+        if stream:
+            got_s[i] = np.concatenate(list(sched.iter_chunks(sched.submit(texts[i], "heart", stream=True))) or [np.zeros(0, np.float32)])
+        else:
+            got_b[i] = sched.synthesize(texts[i], "heart")
+
+    threads = [threading.Thread(target=worker, args=(i, s)) for i in range(4) for s in (True, False)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    sched.close()
+    for i in range(4):
+        assert got_s[i] is not None and got_s[i].shape == want_stream[i].shape, (i, got_s[i].shape, want_stream[i].shape)
+        assert float(np.sqrt(np.mean((got_s[i] - want_stream[i]) ** 2))) <= 1e-6 if got_s[i].size else True
+        assert got_b[i] is not None and got_b[i].shape == want_block[i].shape, (i, got_b[i].shape, want_block[i].shape)
+        assert float(np.sqrt(np.mean((got_b[i] - want_block[i]) ** 2))) <= 1e-6 if got_b[i].size else True
