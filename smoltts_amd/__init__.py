@@ -15,11 +15,13 @@ __version__ = "0.1.0"
 class SmolTTS:
     def __init__(self, model_id: Optional[str] = None, checkpoint_dir: Optional[str] = None,
                  mimi_checkpoint: Optional[str] = None, numerics=None, state=None, config=None, mimi_state=None,
-                 codec_window: int = 0):
+                 codec_window: int = 0, weight_format: str = "bf16"):
         """``checkpoint_dir``: config.json + tokenizer.json + model.safetensors | model.pth (reference
         layouts).  ``mimi_checkpoint``: the Hugging Face kyutai/mimi ``model.safetensors`` (or its
         directory).  ``state``/``config``/``mimi_state`` allow in-memory (e.g. synthetic) weights.
-        ``model_id`` (Hugging Face download in the reference) needs network access and is refused."""
+        ``model_id`` (Hugging Face download in the reference) needs network access and is refused.
+        ``weight_format="fp8"`` stores the Linears as e4m3 with per-row scales (``packing.fp8_reference_state`` is the model
+        then computed)."""
         import torch  # noqa: F401
 
         from .checkpoint import load_checkpoint, load_mimi_state
@@ -41,7 +43,7 @@ class SmolTTS:
         self.config = config
         self.tokenizer = tokenizer
         self.token_config = TokenConfig.from_tokenizer(tokenizer, config)
-        self.lm = LMEngine(config, state, self.token_config, numerics or NumericsMode.torch_reference())
+        self.lm = LMEngine(config, state, self.token_config, numerics or NumericsMode.torch_reference(), weight_format=weight_format)
         self.prompt_encoder = PromptEncoder.from_config(tokenizer, config, self.token_config)
         self.codec = MimiEngine(mimi_state, num_codebooks=config.num_codebooks, window=codec_window, max_positions=2 * (1026 + 64))  # 1025 frames + a scheduler tick of overshoot, 2 positions per frame
         # the encode half (voice-clone prompts) is packed on first use, and only if the checkpoint carries it

@@ -131,7 +131,8 @@ def main():
     from ..config import GenerationSettings
     from .scheduler import BatchScheduler
 
-    model = SmolTTS(checkpoint_dir=settings["checkpoint_dir"], mimi_checkpoint=settings.get("mimi_checkpoint"))
+    model = SmolTTS(checkpoint_dir=settings["checkpoint_dir"], mimi_checkpoint=settings.get("mimi_checkpoint"),
+                    weight_format=settings.get("weight_format", "bf16"))
     gen = settings.get("generation") or {}
     gs = GenerationSettings(default_temp=gen.get("default_temp", 0.5), default_fast_temp=gen.get("default_fast_temp", 0.0),
                             min_p=gen.get("min_p", 0.1), max_new_tokens=gen.get("max_new_tokens", 1024))  # server/settings.py:33-38

@@ -147,3 +147,26 @@ def test_fp8_engine_matches_oracle_on_dequantised_model(cfgname, B, frames):
     other = orc_bf16.generate([torch.from_numpy(prompts[0])], max_frames=frames, stop_on_eos=False)[0].as_tensor().numpy()
     assert not np.array_equal(other, codes[0, :frames].T)
     sess.close(); eng.close()
+
+
+def test_fp8_through_the_facade():
+    from oracle.lm_oracle import LMOracle, OracleLMConfig
+    from oracle.mimi_oracle import MimiDecodeOracle
+    from smoltts_amd import SmolTTS
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+    from smoltts_amd.config import GenerationSettings
+    from smoltts_amd.packing import fp8_reference_state
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+
+    cfg = named_config("tiny")
+    state = synthetic_lm_state(cfg, seed=9)
+    mst = synthetic_mimi_state(seed=1)
+    tts = SmolTTS(state=state, config=cfg, mimi_state=mst, weight_format="fp8")
+    gs = GenerationSettings.greedy(max_new_tokens=7)
+    pcm = tts("quantised weights", "nova", generation_settings=gs)
+    rcfg, rstate = fp8_reference_state(cfg, state)
+    orc = LMOracle(OracleLMConfig.from_dict(rcfg.__dict__), rstate)
+    grid = orc.generate([torch.from_numpy(tts._get_prompt("quantised weights", "nova"))], max_frames=8, stop_on_eos=True)[0].as_tensor()
+    keep = (grid[0] >= 320) & (grid[0] <= 2367)
+    ref = MimiDecodeOracle(mst).decode(grid[1:, keep][None])[0, 0].numpy()
+    assert pcm.shape == ref.shape and float(np.sqrt(np.mean((pcm - ref) ** 2))) <= 1e-4
