@@ -323,11 +323,18 @@ class BatchScheduler:
                     # chunk: then this tick is read as soon as it is done (first-audio latency before pipelining)
                     first_chunk_due = any(r.stream and r.emitted == 0 for r in self._active.values())
                     self._consume_snapshots(keep=0 if first_chunk_due else 1)
+            self._fail_all(RuntimeError("scheduler closed"))  # requests still in flight when close() was called
         except Exception as e:  # engine failure: fail every waiter loudly
-            for r in list(self._active.values()) + self._finished:
+            self._fail_all(e)
+
+    def _fail_all(self, e: Exception) -> None:
+        for r in list(self._active.values()) + self._finished:
+            r.out.put(e)
+        for _, _, items in self._deliveries:
+            for r, _, _, _ in items:
                 r.out.put(e)
-            for _, _, items in self._deliveries:
-                for r, _, _, _ in items:
-                    r.out.put(e)
-            while not self._pending.empty():
-                self._pending.get_nowait().out.put(e)
+        self._active.clear()
+        self._finished = []
+        self._deliveries = []
+        while not self._pending.empty():
+            self._pending.get_nowait().out.put(e)
