@@ -23,6 +23,9 @@
 #include <stdlib.h>
 
 #include "x3.h"
+#ifndef SMOLTTS_DBG_PIECES
+#define SMOLTTS_DBG_PIECES 3
+#endif
 
 namespace smoltts {
 
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
+        for (int pc = 0; pc < SMOLTTS_DBG_PIECES; ++pc)
           xf[u][mt][pc] = (cv && xv[mt]) ? *reinterpret_cast<const uint4*>(xb[mt] + (size_t)c * 3072 + pc * 1024)
                                          : make_uint4(0, 0, 0, 0);
       }
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc)
+          for (int pc = 0; pc < SMOLTTS_DBG_PIECES; ++pc)
             acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8_t, xf[u][mt][pc]), acc[t][mt], 0, 0, 0);
         }
       }
