@@ -44,9 +44,12 @@ class TTSCore:
     def stream_audio(self, input_text: str, voice: Union[str, int]):
         chunks = (self.scheduler.iter_chunks(self.scheduler.submit(input_text, str(voice), stream=True))
                   if self.scheduler is not None else self.model.stream(input_text, str(voice)))
-        for chunk in chunks:
-            if chunk is not None:
-                yield np.asarray(chunk, dtype=np.float32).tobytes()
+        try:
+            for chunk in chunks:
+                if chunk is not None:
+                    yield np.asarray(chunk, dtype=np.float32).tobytes()
+        finally:
+            chunks.close()  # a client that went away mid-stream: the scheduler takes its slot back (BatchScheduler.cancel)
 
     def format_audio_chunk(self, pcm_data: np.ndarray, output_format: str = "pcm_24000"):
         kind, _, rate = output_format.partition("_")

@@ -39,6 +39,8 @@ class _Request:
     pending: list = field(default_factory=list)  # blocking requests: audio-code columns awaiting their codec pass
     prompt: object = None
     first_tick: int = 0  # index of the tick that produces this request's frame 0: older snapshots show the slot's previous tenant
+    cancelled: bool = False  # set by the client side (cancel / an abandoned chunk iterator), honoured by the worker at its next look
+    closed: bool = False  # the end marker (None or an exception) has been queued
 
 
 class BatchScheduler:
@@ -88,13 +90,26 @@ class BatchScheduler:
         return np.concatenate(list(self.iter_chunks(self.submit(text, voice, False, max_new_tokens))) or [np.zeros(0, np.float32)])
 
     def iter_chunks(self, req: _Request):
-        while True:
-            item = req.out.get()
-            if item is None:
-                return
-            if isinstance(item, Exception):
-                raise item
-            yield item
+        """Chunks of one request; abandoning the iterator (a client that went away mid-stream) cancels the request."""
+        ended = False
+        try:
+            while True:
+                item = req.out.get()
+                if item is None or isinstance(item, Exception):
+                    ended = True
+                    if item is None:
+                        return
+                    raise item
+                yield item
+        finally:
+            if not ended:
+                self.cancel(req)
+
+    def cancel(self, req: _Request) -> None:
+        """Stop working for ``req``: its slot is handed to the next request at the worker's next look (within a tick); a
+        request that is still queued never starts.  The slot itself simply keeps decoding until it is restarted — a batch
+        step costs the same with or without it.  Nothing more is delivered except the end marker."""
+        req.cancelled = True
 
     def close(self) -> None:
         self._stop.set()
@@ -110,12 +125,15 @@ class BatchScheduler:
         new: List[_Request] = []
         while self._free and not self._pending.empty():
             req = self._pending.get_nowait()
+            if req.cancelled:
+                self._end(req)
+                continue
             try:
                 req.prompt = self.tts._get_prompt(req.text, req.voice)
                 if req.prompt.shape[1] + req.max_new_tokens + 2 > self.session.max_seq:
                     raise ValueError("prompt + max_new_tokens exceed max_seq_len")
             except Exception as e:  # bad request: answer it, keep serving
-                req.out.put(e)
+                self._end(req, e)
                 continue
             req.slot = self._free.pop(0)
             new.append(req)
@@ -202,6 +220,12 @@ class BatchScheduler:
         nq = self.tts.config.num_codebooks
         tc = self.tts.token_config
         for slot, r in list(self._active.items()):
+            if r.cancelled:  # the client is gone: free the slot now, whatever the snapshot shows
+                del self._active[slot]
+                self._free.append(slot)
+                r.pending = []
+                self._end(r)
+                continue
             if tick_no < r.first_tick:  # the snapshot predates this request: it shows the slot's previous tenant
                 continue
             n = min(int(n_frames[slot]), r.max_new_tokens + 1)
@@ -217,7 +241,7 @@ class BatchScheduler:
                 if finished:
                     del self._active[slot]
                     self._free.append(slot)
-                    r.out.put(None)
+                    self._end(r)
                 continue
             # blocking requests keep only frames whose slow id is a semantic token (generate_blocking, lm/generate.py:196-207)
             slow = codes[slot, r.emitted:n, 0]
@@ -263,6 +287,10 @@ class BatchScheduler:
         if self._batch_codec is None:
             self._batch_codec = MimiSession(self.tts.codec, max_batch=self.CODEC_BATCH, max_chunk_frames=self.CODEC_CHUNK)
         nq = self.tts.config.num_codebooks
+        for r in self._finished:
+            if r.cancelled:
+                self._end(r)
+        self._finished = [r for r in self._finished if not r.cancelled]
         while self._finished:
             batch, self._finished = self._finished[: self.CODEC_BATCH], self._finished[self.CODEC_BATCH:]
             cols = [np.concatenate(r.pending) if r.pending else np.zeros((0, nq), np.int32) for r in batch]
@@ -290,10 +318,10 @@ class BatchScheduler:
                 host = host.numpy()
             self._deliveries.pop(0)
             for r, b, n, fin in items:
-                if n:
+                if n and not r.cancelled:
                     r.out.put(host[b, :n].copy())
                 if fin:
-                    r.out.put(None)
+                    self._end(r)
             wait = False
 
     # ------------------------------------------------------------------ worker: main loop
@@ -327,14 +355,21 @@ class BatchScheduler:
         except Exception as e:  # engine failure: fail every waiter loudly
             self._fail_all(e)
 
+    @staticmethod
+    def _end(r: _Request, e: Optional[Exception] = None) -> None:
+        """Queue the end marker of a request (exactly once)."""
+        if not r.closed:
+            r.closed = True
+            r.out.put(e)
+
     def _fail_all(self, e: Exception) -> None:
         for r in list(self._active.values()) + self._finished:
-            r.out.put(e)
+            self._end(r, e)
         for _, _, items in self._deliveries:
             for r, _, _, _ in items:
-                r.out.put(e)
+                self._end(r, e)
         self._active.clear()
         self._finished = []
         self._deliveries = []
         while not self._pending.empty():
-            self._pending.get_nowait().out.put(e)
+            self._end(self._pending.get_nowait(), e)

@@ -96,3 +96,45 @@ def test_scheduler_stops_on_eos_like_the_facade():
         assert float(np.sqrt(np.mean((got_s[i] - want_stream[i]) ** 2))) <= 1e-6 if got_s[i].size else True
         assert got_b[i] is not None and got_b[i].shape == want_block[i].shape, (i, got_b[i].shape, want_block[i].shape)
         assert float(np.sqrt(np.mean((got_b[i] - want_block[i]) ** 2))) <= 1e-6 if got_b[i].size else True
+
+
+def test_scheduler_cancel_frees_the_slot_and_leaves_the_others_alone():
+    """A client that abandons its stream (or its queued request) gives the slot back within a tick; whoever gets the slot
+    next, and the requests decoding beside it, still receive exactly the single-request audio."""
+    import time
+
+    from smoltts_amd import SmolTTS
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+    from smoltts_amd.config import GenerationSettings
+    from smoltts_amd.server.scheduler import BatchScheduler
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+
+    cfg = named_config("tiny")
+    tts = SmolTTS(state=synthetic_lm_state(cfg, seed=21), config=cfg, mimi_state=synthetic_mimi_state(seed=5))
+    gs = GenerationSettings.greedy(max_new_tokens=300)  # long enough that nobody finishes by themselves meanwhile
+    want_long = np.concatenate(list(tts.stream("the neighbour keeps talking", "sky", generation_settings=gs)))
+    assert want_long.shape[0] == 301 * 1920  # no <|im_end|> on the way: the victim below would run as long
+    want_next = tts("takes over the abandoned slot", "nova", generation_settings=GenerationSettings.greedy(max_new_tokens=9))
+    sched = BatchScheduler(tts, max_batch=2, frames_per_tick=2, generation_settings=gs)
+    try:
+        neighbour = sched.submit("the neighbour keeps talking", "sky", stream=True)
+        victim = sched.submit("this client hangs up early", "heart", stream=True)
+        queued = sched.submit("never gets a slot", "liam", stream=False)  # both slots are taken: it waits
+        sched.cancel(queued)
+        it = sched.iter_chunks(victim)
+        first = next(it)
+        assert first.shape[0] % 1920 == 0 and first.shape[0] > 0
+        it.close()  # what a dropped HTTP connection does to the response generator
+        assert victim.cancelled
+        t0 = time.time()
+        got_next = sched.synthesize("takes over the abandoned slot", "nova", max_new_tokens=9)  # needs the victim's slot
+        assert time.time() - t0 < 30
+        got_long = np.concatenate(list(sched.iter_chunks(neighbour)))
+        assert got_next.shape == want_next.shape and float(np.sqrt(np.mean((got_next - want_next) ** 2))) <= 1e-6
+        assert got_long.shape == want_long.shape and float(np.sqrt(np.mean((got_long - want_long) ** 2))) <= 1e-6
+        assert list(sched.iter_chunks(queued)) == []  # ended without audio, without an error
+        # the victim's queue ends too (a reader that comes back later does not block for ever)
+        rest = list(sched.iter_chunks(victim))
+        assert first.shape[0] + sum(c.shape[0] for c in rest) < 200 * 1920  # cut short, not played out
+    finally:
+        sched.close()
