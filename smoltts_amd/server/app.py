@@ -120,26 +120,27 @@ def create_app(model=None, settings: Optional[dict] = None, scheduler=None) -> F
 
 
 def main():
-    import uvicorn
+    import functools
 
-    from .. import SmolTTS
+    import uvicorn
 
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=str, help="settings JSON: {checkpoint_dir, mimi_checkpoint, generation{...}, model_type{...}}")
     ap.add_argument("--port", type=int, default=8000)
+    ap.add_argument("--gpus", type=int, default=1, help="worker processes, one per GPU (request-level data parallelism); 1 = serve from this process")
     args = ap.parse_args()
     settings = json.loads(open(args.config).read()) if args.config else {}
     if not settings.get("checkpoint_dir"):
         raise SystemExit("settings must name checkpoint_dir (model_id downloads need network access)")
-    from ..config import GenerationSettings
-    from .scheduler import BatchScheduler
+    from .pool import GpuPool, scheduler_from_settings
 
-    model = SmolTTS(checkpoint_dir=settings["checkpoint_dir"], mimi_checkpoint=settings.get("mimi_checkpoint"),
-                    weight_format=settings.get("weight_format", "bf16"))
-    gen = settings.get("generation") or {}
-    gs = GenerationSettings(default_temp=gen.get("default_temp", 0.5), default_fast_temp=gen.get("default_fast_temp", 0.0),
-                            min_p=gen.get("min_p", 0.1), max_new_tokens=gen.get("max_new_tokens", 1024))  # server/settings.py:33-38
-    sched = BatchScheduler(model, max_batch=int(settings.get("max_batch", 32)), generation_settings=gs)
+    if args.gpus > 1:
+        # this process stays off the GPUs: it parses HTTP and relays audio; every worker owns one GPU and one scheduler
+        sched = GpuPool(functools.partial(scheduler_from_settings, settings), devices=list(range(args.gpus)))
+        model = None
+    else:
+        sched = scheduler_from_settings(settings)
+        model = sched.tts
     uvicorn.run(create_app(model, settings, sched), host="0.0.0.0", port=args.port)
 
 
