@@ -43,11 +43,23 @@ def visible_device(index: int, inherited: Optional[str]) -> str:
     return str(index)
 
 
-def _worker_main(device: str, factory: Callable[[], object], req_q, res_q) -> None:
+class _Sender:
+    """The worker's end of its result pipe; several pump threads share it."""
+
+    def __init__(self, conn):
+        self.conn, self.lock = conn, threading.Lock()
+
+    def put(self, msg) -> None:
+        with self.lock:
+            self.conn.send(msg)
+
+
+def _worker_main(device: str, factory: Callable[[], object], req_q, res_conn) -> None:
     """Worker process: build the scheduler on its GPU, then serve messages until told to close.  ``factory()`` returns an
     object with the BatchScheduler client interface (it is called here, after the device mask is in place and before
     anything has touched the GPU)."""
     os.environ["HIP_VISIBLE_DEVICES"] = device
+    res_q = _Sender(res_conn)
     try:
         sched = factory()
     except BaseException as e:  # the front-end must hear about a worker that cannot start
@@ -99,37 +111,45 @@ class GpuPool:
             raise ValueError("no devices")
         ctx = mp.get_context(start_method)
         inherited = os.environ.get("HIP_VISIBLE_DEVICES")
-        self._res_q = ctx.Queue()
         self._req_qs = [ctx.Queue() for _ in devices]
-        self._procs = [ctx.Process(target=_worker_main, args=(visible_device(d, inherited), factory, q, self._res_q), daemon=True,
-                                   name=f"smoltts-gpu-worker-{i}") for i, (d, q) in enumerate(zip(devices, self._req_qs))]
+        pipes = [ctx.Pipe(duplex=False) for _ in devices]  # one result pipe per worker: no shared lock, EOF when a worker dies
+        self._res = [r for r, _ in pipes]
+        self._procs = [ctx.Process(target=_worker_main, args=(visible_device(d, inherited), factory, q, w), daemon=True,
+                                   name=f"smoltts-gpu-worker-{i}") for i, (d, q, (_, w)) in enumerate(zip(devices, self._req_qs, pipes))]
         for p in self._procs:
             p.start()
+        for _, w in pipes:
+            w.close()  # the workers hold the write ends now
         self._lock = threading.Lock()
         self._reqs: Dict[int, _PoolRequest] = {}
         self._load: List[int] = [0] * len(devices)
+        self._dead: List[bool] = [False] * len(devices)  # set (under the lock) by a worker's dispatcher when its pipe ends
         self._ids = itertools.count()
         self._closing = False
-        ready = 0
-        while ready < len(devices):  # all workers up (weights loaded, kernels resident) before the first request is taken
+        for i, conn in enumerate(self._res):  # all workers up (weights loaded, kernels resident) before the first request is taken
             try:
-                rid, kind, payload = self._res_q.get(timeout=ready_timeout)
-            except queue.Empty:
+                if not conn.poll(ready_timeout):
+                    raise RuntimeError("GPU workers did not come up in time")
+                _, kind, payload = conn.recv()
+            except EOFError:
+                kind, payload = "fatal", f"worker {i} exited during start-up"
+            except RuntimeError:
                 self._kill()
-                raise RuntimeError("GPU workers did not come up in time")
-            if kind == "fatal":
+                raise
+            if kind != "ready":
                 self._kill()
                 raise RuntimeError(f"GPU worker failed to start: {payload}")
-            ready += kind == "ready"
-        self._thread = threading.Thread(target=self._dispatch, name="smoltts-pool-dispatch", daemon=True)
-        self._thread.start()
+        self._threads = [threading.Thread(target=self._dispatch, args=(i,), name=f"smoltts-pool-dispatch-{i}", daemon=True)
+                         for i in range(len(devices))]
+        for t in self._threads:
+            t.start()
 
     # ------------------------------------------------------------------ client side (the BatchScheduler interface)
     def submit(self, text: str, voice: str = "heart", stream: bool = False, max_new_tokens: Optional[int] = None) -> _PoolRequest:
         with self._lock:
             if self._closing:
                 raise RuntimeError("pool closed")
-            alive = [i for i, p in enumerate(self._procs) if p.is_alive()]
+            alive = [i for i, p in enumerate(self._procs) if not self._dead[i] and p.is_alive()]
             if not alive:
                 raise RuntimeError("no GPU worker is alive")
             w = min(alive, key=lambda i: self._load[i])
@@ -175,8 +195,8 @@ class GpuPool:
         for p in self._procs:
             p.join(timeout=60)
         self._kill()
-        self._res_q.put((None, "stop", None))
-        self._thread.join(timeout=10)
+        for t in self._threads:  # every dispatcher sees the end of its pipe once its worker is gone
+            t.join(timeout=10)
         self._fail_open(RuntimeError("pool closed"))
 
     # ------------------------------------------------------------------ front-end internals
@@ -195,17 +215,17 @@ class GpuPool:
         for r in reqs:
             self._finish(r, e)
 
-    def _dispatch(self) -> None:
-        """Relay worker output to the waiting clients; notice workers that died with requests in flight."""
+    def _dispatch(self, w: int) -> None:
+        """Relay worker ``w``'s output to the waiting clients; the end of its pipe means the worker is gone."""
+        conn = self._res[w]
         while True:
             try:
-                rid, kind, payload = self._res_q.get(timeout=0.5)
-            except queue.Empty:
-                for i, p in enumerate(self._procs):
-                    if not p.is_alive() and self._load[i] and not self._closing:
-                        self._fail_open(RuntimeError(f"GPU worker {i} died (exit code {p.exitcode})"), worker=i)
-                continue
-            if kind == "stop":
+                rid, kind, payload = conn.recv()
+            except (EOFError, OSError):
+                with self._lock:
+                    self._dead[w] = True  # from here on submit() avoids this worker; what it holds is failed just below
+                if not self._closing:
+                    self._fail_open(RuntimeError(f"GPU worker {w} died (exit code {self._procs[w].exitcode})"), worker=w)
                 return
             with self._lock:
                 req = self._reqs.get(rid)
