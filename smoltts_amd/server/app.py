@@ -4,8 +4,8 @@ Routes, schemas, headers and status behaviour follow mlx_inference/src/smoltts_m
 openai.py:6-28 (``POST /v1/audio/speech`` -> audio/wav attachment ``speech.wav``) and elevenlabs.py:14-63
 (``POST /v1/text-to-speech/{voice_id}`` blocking with ``output_format`` pcm_*/wav_*; ``.../stream`` ->
 chunked raw float32 PCM with ``X-Sample-Rate: 24000``), ``TTSCore`` (server/tts_core.py:15-84) and the
-settings file (server/settings.py:12-63).  mp3 output and resampling need pydub/soundfile, which the
-reference pulls in and this image lacks: those formats answer 501 instead of being half-implemented.
+settings file (server/settings.py:12-63).  mp3 output needs pydub + ffmpeg, which the reference pulls in and this image
+lacks: those formats answer 501 instead of being half-implemented.
 """
 from __future__ import annotations
 
@@ -52,17 +52,25 @@ class TTSCore:
             chunks.close()  # a client that went away mid-stream: the scheduler takes its slot back (BatchScheduler.cancel)
 
     def format_audio_chunk(self, pcm_data: np.ndarray, output_format: str = "pcm_24000"):
+        """tts_core.py:49-84: resample when the format names another rate (FFT resampling, ``scipy.signal.resample``, as
+        there), then raw PCM16 (rounded, as libsndfile writes it there), WAV (io/wav.py framing) or mp3 (not available)."""
         kind, _, rate = output_format.partition("_")
         sample_rate = int(rate.split("_")[0]) if rate else 24000
-        if sample_rate != 24000:
-            raise HTTPException(status_code=501, detail="resampling is not available in this build (24000 Hz only)")
-        if kind == "pcm":
-            return (np.clip(pcm_data, -1.0, 1.0) * 32767).astype(np.int16).tobytes(), "audio/x-pcm"
-        if kind == "wav":
-            return pcm_to_wav_bytes(pcm_data, sample_rate), "audio/wav"
+        pcm_data = np.asarray(pcm_data, dtype=np.float32).reshape(-1)
+        if kind not in ("pcm", "wav", "mp3"):
+            raise HTTPException(status_code=400, detail=f"Format {output_format} not yet supported")
         if kind == "mp3":
-            raise HTTPException(status_code=501, detail="mp3 output is not available in this build")
-        raise HTTPException(status_code=400, detail=f"Format {output_format} not yet supported")
+            raise HTTPException(status_code=501, detail="mp3 output is not available in this build (no encoder in the image)")
+        if sample_rate != 24000:
+            if sample_rate <= 0:
+                raise HTTPException(status_code=400, detail=f"bad sample rate in {output_format}")
+            from scipy import signal
+
+            n = int(len(pcm_data) * sample_rate / 24000)
+            pcm_data = signal.resample(pcm_data, n).astype(np.float32) if n > 0 else np.zeros(0, np.float32)
+        if kind == "pcm":
+            return np.rint(np.clip(pcm_data, -1.0, 1.0) * 32767).astype(np.int16).tobytes(), "audio/x-pcm"
+        return pcm_to_wav_bytes(pcm_data, sample_rate), "audio/wav"
 
 
 class SpeechRequest(BaseModel):
@@ -90,7 +98,7 @@ def openai_speech(item: SpeechRequest, http_request: Request):
 
 @eleven_router.post("/text-to-speech/{voice_id}")
 def text_to_speech_blocking(voice_id: str, item: CreateSpeechRequest, http_request: Request,
-                                  output_format: Optional[str] = Query(None, description="pcm_24000 | wav_24000")):
+                                  output_format: Optional[str] = Query(None, description="pcm_<rate> | wav_<rate>")):
     core = http_request.app.state.tts_core
     fmt = output_format or "wav_24000"
     content, media_type = core.generate_audio(item.text, voice_id, fmt)

@@ -54,3 +54,26 @@ def test_elevenlabs_routes(client):
     chunks = np.frombuffer(r.content, dtype=np.float32)
     assert chunks.shape == (3 * 1920,) and np.allclose(chunks[1920:1922], 0.1)
     assert client.post("/v1/text-to-speech/3?output_format=mp3_44100_128", json={"text": "abc"}).status_code == 501
+    # other sample rates are FFT-resampled as in the reference (tts_core.py:56-59)
+    r = client.post("/v1/text-to-speech/3?output_format=pcm_16000", json={"text": "abc"})
+    assert r.status_code == 200 and r.headers["x-sample-rate"] == "16000" and len(r.content) == 2 * (3 * 1920 * 16000 // 24000)
+    r = client.post("/v1/text-to-speech/3?output_format=wav_44100", json={"text": "abc"})
+    assert r.status_code == 200 and r.content[:4] == b"RIFF" and struct.unpack("<I", r.content[24:28])[0] == 44100
+    assert len(r.content) == 44 + 2 * int(3 * 1920 * 44100 / 24000)
+    assert client.post("/v1/text-to-speech/3?output_format=flac_24000", json={"text": "abc"}).status_code == 400
+
+
+def test_resampling_follows_scipy_fft_resample():
+    from scipy import signal
+
+    from smoltts_amd.server.app import TTSCore
+
+    t = np.arange(4800) / 24000.0
+    pcm = (0.5 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+    data, media = TTSCore(None).format_audio_chunk(pcm, "pcm_8000")
+    got = np.frombuffer(data, dtype=np.int16)
+    want = np.rint(np.clip(signal.resample(pcm, 1600), -1, 1) * 32767).astype(np.int16)
+    assert media == "audio/x-pcm" and got.shape == want.shape and int(np.abs(got.astype(int) - want.astype(int)).max()) <= 1
+    # still a 440 Hz tone of the same amplitude
+    spec = np.abs(np.fft.rfft(got.astype(np.float64)))
+    assert abs(int(spec.argmax()) * 8000 / 1600 - 440) <= 5 and abs(np.abs(got).max() / 32767 - 0.5) < 0.01
