@@ -137,10 +137,15 @@ def main():
     ap.add_argument("--port", type=int, default=8000)
     ap.add_argument("--gpus", type=int, default=1, help="worker processes, one per GPU (request-level data parallelism); 1 = serve from this process")
     args = ap.parse_args()
-    settings = json.loads(open(args.config).read()) if args.config else {}
-    if not settings.get("checkpoint_dir"):
-        raise SystemExit("settings must name checkpoint_dir (model_id downloads need network access)")
     from .pool import GpuPool, scheduler_from_settings
+    from .settings import ServerSettings
+
+    try:
+        settings = ServerSettings.get_settings(args.config)
+        settings.get_checkpoint_dir()
+    except ValueError as e:
+        raise SystemExit(f"settings: {e}")
+    settings = settings.model_dump()  # plain data: it travels to the worker processes
 
     if args.gpus > 1:
         # this process stays off the GPUs: it parses HTTP and relays audio; every worker owns one GPU and one scheduler

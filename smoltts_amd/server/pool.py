@@ -248,18 +248,16 @@ class GpuPool:
 
 
 # ---------------------------------------------------------------------- factories (picklable: module-level callables)
-def scheduler_from_settings(settings: dict):
-    """What a worker of ``smoltts-server --gpus N`` builds: the model from the settings file, and its scheduler."""
+def scheduler_from_settings(settings):
+    """What a worker of ``smoltts-server --gpus N`` builds: the model from the settings file (a ``ServerSettings`` or the
+    dict it is made from), and its scheduler."""
     from .. import SmolTTS
-    from ..config import GenerationSettings
     from .scheduler import BatchScheduler
+    from .settings import ServerSettings
 
-    model = SmolTTS(checkpoint_dir=settings["checkpoint_dir"], mimi_checkpoint=settings.get("mimi_checkpoint"),
-                    weight_format=settings.get("weight_format", "bf16"))
-    gen = settings.get("generation") or {}
-    gs = GenerationSettings(default_temp=gen.get("default_temp", 0.5), default_fast_temp=gen.get("default_fast_temp", 0.0),
-                            min_p=gen.get("min_p", 0.1), max_new_tokens=gen.get("max_new_tokens", 1024))  # server/settings.py:33-38
-    return BatchScheduler(model, max_batch=int(settings.get("max_batch", 32)), generation_settings=gs)
+    st = settings if isinstance(settings, ServerSettings) else ServerSettings(**settings)
+    model = SmolTTS(checkpoint_dir=str(st.get_checkpoint_dir()), mimi_checkpoint=st.mimi_checkpoint, weight_format=st.weight_format)
+    return BatchScheduler(model, max_batch=st.max_batch, generation_settings=st.generation.to_settings())
 
 
 def synthetic_scheduler(model: str = "tiny", seed: int = 21, mimi_seed: int = 5, max_batch: int = 4, frames_per_tick: int = 2,

@@ -77,3 +77,32 @@ def test_resampling_follows_scipy_fft_resample():
     # still a 440 Hz tone of the same amplitude
     spec = np.abs(np.fft.rfft(got.astype(np.float64)))
     assert abs(int(spec.argmax()) * 8000 / 1600 - 440) <= 5 and abs(np.abs(got).max() / 32767 - 0.5) < 0.01
+
+
+def test_settings_schema_follows_the_reference(tmp_path):
+    """server/settings.py:12-25: exactly one model source; generation defaults 0.5 / 0.0 / 0.10 / 1024 (:33-38)."""
+    import json
+
+    from smoltts_amd.server.settings import ServerSettings
+
+    p = tmp_path / "config.json"
+    p.write_text(json.dumps({"checkpoint_dir": "/ckpt", "model_type": {"family": "dual_ar", "codec": "mimi", "version": None},
+                             "generation": {"default_temp": 0.3, "default_fast_temp": 0.0, "min_p": 0.05, "max_new_tokens": 512},
+                             "mimi_checkpoint": "/mimi", "weight_format": "fp8"}))
+    st = ServerSettings.get_settings(str(p))
+    gs = st.generation.to_settings()
+    assert str(st.get_checkpoint_dir()) == "/ckpt" and (gs.default_temp, gs.default_fast_temp, gs.min_p, gs.max_new_tokens) == (0.3, 0.0, 0.05, 512)
+    assert st.weight_format == "fp8" and st.max_batch == 32
+    d = ServerSettings(checkpoint_dir="/ckpt").generation
+    assert (d.default_temp, d.default_fast_temp, d.min_p, d.max_new_tokens) == (0.5, 0.0, 0.10, 1024)
+    with pytest.raises(ValueError, match="both"):
+        ServerSettings(model_id="jkeisling/smoltts_v0", checkpoint_dir="/ckpt")
+    with pytest.raises(ValueError, match="either"):
+        ServerSettings()
+    with pytest.raises(ValueError, match="network"):
+        ServerSettings(model_id="jkeisling/smoltts_v0").get_checkpoint_dir()
+    with pytest.raises(ValueError):
+        ServerSettings(checkpoint_dir="/ckpt", model_type={"family": "fish", "codec": "1.4", "version": "1.4"})
+    with pytest.raises(ValueError):
+        ServerSettings.get_settings(None)
+    assert ServerSettings(**st.model_dump()) == st  # what travels to the worker processes rebuilds the same settings
