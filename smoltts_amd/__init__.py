@@ -15,7 +15,7 @@ __version__ = "0.1.0"
 class SmolTTS:
     def __init__(self, model_id: Optional[str] = None, checkpoint_dir: Optional[str] = None,
                  mimi_checkpoint: Optional[str] = None, numerics=None, state=None, config=None, mimi_state=None,
-                 codec_window: int = 0, weight_format: str = "bf16"):
+                 codec_window: int = 0, weight_format: str = "bf16", verbose: bool = False):
         """``checkpoint_dir``: config.json + tokenizer.json + model.safetensors | model.pth (reference
         layouts).  ``mimi_checkpoint``: the Hugging Face kyutai/mimi ``model.safetensors`` (or its
         directory).  ``state``/``config``/``mimi_state`` allow in-memory (e.g. synthetic) weights.
@@ -51,6 +51,8 @@ class SmolTTS:
         self._codec_window = codec_window
         self._encoder = None
         self.sampling_rate = 24_000
+        self.verbose = verbose  # print the reference's per-call timing lines (lm/generate.py:187-214)
+        self.last_stats: dict = {}  # timing of the last generate_codes / __call__ (BatchGenerator.stats + codec_ms)
 
     # -- prompt (``_get_prompt``, __init__.py:120-151)
     def _get_prompt(self, input: str, voice: str, sysprompt=None):
@@ -77,7 +79,13 @@ class SmolTTS:
             for b, tok in enumerate(row):
                 if tok is not None and tok.audio_codes is not None:
                     cols[b].append(tok.audio_codes[0, :, 0])
+        self.last_stats = gen.stats()
         gen.close()
+        if self.verbose and self.last_stats:
+            st = self.last_stats
+            print(f"Prompt: {st['prompt_tokens']} tokens in {st['prefill_ms']:.1f} ms ({st['prefill_tokens_per_s']:.0f} tokens/s)")
+            print(f"Generated {st['frames']} frames: {st['frames_per_s']:.1f} frames/s, {st['ms_per_frame_step']:.3f} ms/frame-step, "
+                  f"{st['realtime_x']:.1f}x realtime")
         nq = self.config.num_codebooks
         return [np.stack(c, axis=1).astype(np.uint32) if c else np.zeros((nq, 0), np.uint32) for c in cols]
 
@@ -91,10 +99,16 @@ class SmolTTS:
         F_ = int(codes.shape[1])
         if F_ == 0:
             return np.zeros(0, np.float32)
+        import time
+
+        t0 = time.perf_counter()
         sess = MimiSession(self.codec, max_batch=1, max_chunk_frames=min(16, F_))
         dev = torch.from_numpy(np.ascontiguousarray(codes.T.astype(np.int32)))[None].cuda()
         pcm = sess.decode(dev).cpu().numpy().reshape(-1)
         sess.close()
+        self.last_stats = dict(self.last_stats, codec_ms=(time.perf_counter() - t0) * 1e3, codec_frames=F_)
+        if self.verbose:
+            print(f"Decoded {F_} frames to PCM in {self.last_stats['codec_ms']:.1f} ms")
         return pcm
 
     def __call__(self, input: str, voice: Optional[str] = "heart", speaker=None, generation_settings=None):

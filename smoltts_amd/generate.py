@@ -19,6 +19,7 @@ from dataclasses import dataclass
 from typing import Any, List, Optional, Sequence
 
 import numpy as np
+import torch
 
 from .config import GenerationSettings
 from .engine import LMEngine, LMSession
@@ -74,6 +75,9 @@ class BatchGenerator:
         self._emitted = np.zeros(self.B, dtype=np.int64)
         self._per_sync = max(1, frames_per_sync)
         self._pending: List[List[Optional[VQToken]]] = []
+        # wall-clock figures of the reference (prefill ms, frames/s, x realtime: lm/generate.py:187-214), from events on the
+        # launch stream so that measuring does not add a synchronisation
+        self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]  # before prefill, after it, after the last decode
 
     def __iter__(self):
         return self
@@ -81,12 +85,15 @@ class BatchGenerator:
     def _run(self) -> None:
         s = self.session
         if not self._started:
+            self._ev[0].record()
             s.prefill(self._prompts, stop_on_eos=self.audio_only)
+            self._ev[1].record()
             self._started = True
             if self._per_sync > 1:
                 s.decode(self._per_sync - 1)
         else:
             s.decode(self._per_sync)
+        self._ev[2].record()
         codes, n_frames, done, _ = s.fetch()
         top = int(n_frames.max())
         lo = int(self._emitted.min()) if (n_frames > self._emitted).any() else top
@@ -112,6 +119,23 @@ class BatchGenerator:
             if not self._pending:
                 raise StopIteration
         return self._pending.pop(0)
+
+    def stats(self) -> dict:
+        """Prefill time (prompt -> frame 0) and decode rate of what has run so far; the rate is the reference's
+        "x realtime": frames after the first / 12.5 / decode seconds, summed over the batch (prefill and codec excluded)."""
+        if not self._started:
+            return {}
+        torch.cuda.current_stream().synchronize()
+        prefill_ms = self._ev[0].elapsed_time(self._ev[1])
+        decode_s = self._ev[1].elapsed_time(self._ev[2]) / 1e3
+        frames = int(self._emitted.sum())
+        after_first = max(frames - self.B, 0)
+        rate = after_first / decode_s if decode_s > 0 and after_first else 0.0
+        n_prompt = sum(int(p.shape[1]) for p in self._prompts)
+        return {"utterances": self.B, "prompt_tokens": n_prompt, "prefill_ms": prefill_ms,
+                "prefill_tokens_per_s": n_prompt / (prefill_ms / 1e3) if prefill_ms > 0 else 0.0, "frames": frames,
+                "decode_s": decode_s, "frames_per_s": rate, "ms_per_frame_step": 1e3 * decode_s / max(after_first / self.B, 1e-9) if after_first else 0.0,
+                "realtime_x": rate / 12.5}
 
     def close(self) -> None:
         self.session.close()

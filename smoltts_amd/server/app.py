@@ -115,6 +115,13 @@ def stream_tts(voice_id: str, item: CreateSpeechRequest, http_request: Request,
         "Content-Disposition": 'attachment; filename="speech.pcm"', "X-Sample-Rate": "24000"})
 
 
+@eleven_router.get("/stats")
+def stats(http_request: Request):
+    """Not in the reference: serving counters (requests by outcome, frames delivered, slots in use) of the scheduler or pool."""
+    sched = http_request.app.state.tts_core.scheduler
+    return sched.stats() if sched is not None and hasattr(sched, "stats") else {}
+
+
 def create_app(model=None, settings: Optional[dict] = None, scheduler=None) -> FastAPI:
     """``model``: a ``smoltts_amd.SmolTTS`` (or any object with ``__call__``/``stream``); ``scheduler``: an
     optional ``BatchScheduler`` so that concurrent requests are decoded together (handlers are plain

@@ -182,6 +182,12 @@ class GpuPool:
             req.cancelled = True
             self._req_qs[req.worker].put(("cancel", req.rid))
 
+    def stats(self) -> dict:
+        """Front-end view (``GET /v1/stats``): workers alive and requests in flight per worker."""
+        with self._lock:
+            return {"workers": len(self._procs), "alive": sum(1 for i, p in enumerate(self._procs) if not self._dead[i] and p.is_alive()),
+                    "in_flight": list(self._load)}
+
     def loads(self) -> List[int]:
         """Requests in flight per worker."""
         with self._lock:

@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import queue
 import threading
+import time
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -76,6 +77,8 @@ class BatchScheduler:
         self._deliveries: List[tuple] = []      # (event, pcm on the device, [(request, first sample, n samples, last?)]) in order
         self._snaps: List[tuple] = []           # snapshots of the output ring the host has not looked at yet (oldest first)
         self._tick_no = 0                       # ticks queued so far
+        self._counts = {"completed": 0, "cancelled": 0, "failed": 0, "frames_delivered": 0}
+        self._t0 = time.time()
         self._thread = threading.Thread(target=self._run, name="smoltts-scheduler", daemon=True)
         self._thread.start()
 
@@ -237,6 +240,7 @@ class BatchScheduler:
                 if k > 0:
                     assert pcm is not None and r.emitted == (tick_no - r.first_tick) * self.tick, "stream bookkeeping out of step"
                     r.out.put(pcm[slot, : k * 1920].copy())
+                    self._counts["frames_delivered"] += k
                 r.emitted = n
                 if finished:
                     del self._active[slot]
@@ -320,6 +324,7 @@ class BatchScheduler:
             for r, b, n, fin in items:
                 if n and not r.cancelled:
                     r.out.put(host[b, :n].copy())
+                    self._counts["frames_delivered"] += n // 1920
                 if fin:
                     self._end(r)
             wait = False
@@ -355,12 +360,20 @@ class BatchScheduler:
         except Exception as e:  # engine failure: fail every waiter loudly
             self._fail_all(e)
 
-    @staticmethod
-    def _end(r: _Request, e: Optional[Exception] = None) -> None:
+    def _end(self, r: _Request, e: Optional[Exception] = None) -> None:
         """Queue the end marker of a request (exactly once)."""
         if not r.closed:
             r.closed = True
+            self._counts["failed" if e is not None else ("cancelled" if r.cancelled else "completed")] += 1
             r.out.put(e)
+
+    def stats(self) -> dict:
+        """Counters since start (served by ``GET /v1/stats``): requests by outcome, audio frames handed to clients, ticks,
+        slots in use, queue length."""
+        up = time.time() - self._t0
+        return dict(self._counts, ticks=self._tick_no, frames_per_tick=self.tick, slots=self.B, active=len(self._active),
+                    queued=self._pending.qsize(), awaiting_codec=len(self._finished), uptime_s=up,
+                    delivered_frames_per_s=self._counts["frames_delivered"] / up if up > 0 else 0.0)
 
     def _fail_all(self, e: Exception) -> None:
         for r in list(self._active.values()) + self._finished:

@@ -87,3 +87,23 @@ def test_generate_blocking_and_pth_checkpoint(setup):
     # slow sampled, depth greedy (the server's defaults: temp 0.5, fast temp 0.0)
     s4 = generate_blocking(tts.lm, prompt, GenerationSettings(default_temp=0.5, default_fast_temp=0.0, min_p=0.1, max_new_tokens=7, seed=1), audio_only=False)
     assert s4.shape == (1, 9, 8)
+
+
+def test_call_reports_the_reference_timing_figures(setup, capsys):
+    """lm/generate.py:187-214 prints prefill ms / tokens per s and frames per s / ms per frame / x realtime; here the same
+    figures are kept in ``last_stats`` (and printed with ``verbose``)."""
+    from smoltts_amd.config import GenerationSettings
+
+    cfg, state, mst, tts, orc, morc, _ = setup
+    tts.verbose = True
+    try:
+        pcm = tts("Hello world!", "sky", generation_settings=GenerationSettings.greedy(max_new_tokens=9))
+    finally:
+        tts.verbose = False
+    st = tts.last_stats
+    assert st["utterances"] == 1 and st["prompt_tokens"] == 24 and st["frames"] == 10  # 5 + 16 + 3 prompt columns (SURVEY §8a-2)
+    assert st["prefill_ms"] > 0 and st["decode_s"] > 0 and st["frames_per_s"] > 0
+    assert abs(st["realtime_x"] - st["frames_per_s"] / 12.5) < 1e-9
+    assert st["codec_frames"] == pcm.shape[0] // 1920 and st["codec_ms"] > 0
+    out = capsys.readouterr().out
+    assert "Prompt: 24 tokens" in out and "x realtime" in out and "to PCM" in out

@@ -48,7 +48,7 @@ def test_pool_routes_relays_and_balances():
             assert len(set(g[:, 0])) == 1  # one worker served the whole request
             served.append(int(g[0, 0]))
         assert sorted(set(served)) == [0, 1]  # both workers were used, each under its own device mask
-        assert pool.loads() == [0, 0]
+        assert pool.loads() == [0, 0] and pool.stats() == {"workers": 2, "alive": 2, "in_flight": [0, 0]}
         assert pool.synthesize("abcd", max_new_tokens=2).shape == (8,)
         # an error raised for one request reaches that client only
         with pytest.raises(RuntimeError, match="bad request"):

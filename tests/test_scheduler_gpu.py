@@ -136,5 +136,8 @@ def test_scheduler_cancel_frees_the_slot_and_leaves_the_others_alone():
         # the victim's queue ends too (a reader that comes back later does not block for ever)
         rest = list(sched.iter_chunks(victim))
         assert first.shape[0] + sum(c.shape[0] for c in rest) < 200 * 1920  # cut short, not played out
+        st = sched.stats()
+        assert st["completed"] == 2 and st["cancelled"] == 2 and st["failed"] == 0 and st["active"] == 0 and st["queued"] == 0
+        assert st["frames_delivered"] >= (want_next.shape[0] + want_long.shape[0]) // 1920
     finally:
         sched.close()

@@ -61,6 +61,7 @@ def test_elevenlabs_routes(client):
     assert r.status_code == 200 and r.content[:4] == b"RIFF" and struct.unpack("<I", r.content[24:28])[0] == 44100
     assert len(r.content) == 44 + 2 * int(3 * 1920 * 44100 / 24000)
     assert client.post("/v1/text-to-speech/3?output_format=flac_24000", json={"text": "abc"}).status_code == 400
+    assert client.get("/v1/stats").json() == {}  # no scheduler behind this app: nothing to count
 
 
 def test_resampling_follows_scipy_fft_resample():

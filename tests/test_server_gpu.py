@@ -42,6 +42,8 @@ def test_routes_with_scheduler_and_concurrent_clients():
         t.start()
     for t in threads:
         t.join(timeout=120)
+    st = client.get("/v1/stats").json()
+    assert st["completed"] == len(texts) + 3 and st["failed"] == 0 and st["slots"] == 4 and st["frames_delivered"] > 0
     sched.close()
     for i, w in enumerate(want_pcm):
         r = got[("speech", i)]
