@@ -29,6 +29,8 @@ struct SmolttsEngine {
   size_t arena_bytes;
 };
 
+constexpr int STAGE_RING = 8;
+
 struct SmolttsSession {
   SmolttsEngine* e;
   int B, max_seq, max_rows, max_frames;
@@ -52,9 +54,10 @@ struct SmolttsSession {
   float* margin;             // [B]
   int* codes;                // [B][max_frames][1+n_fast]
   // host staging (pinned)
-  int* h_stage;
-  hipEvent_t stage_ev;         // recorded behind the async copies out of h_stage
-  bool stage_ev_live;
+  int* h_stage;                // STAGE_RING pinned areas of 2*B ints, used in turn
+  hipEvent_t stage_ev[8];      // recorded behind the async copies out of each area
+  bool stage_ev_live[8];
+  int stage_next;
   hipGraphExec_t graph_exec;   // one decode frame (slow step + tail)
   bool graph_ready;
   hipGraphExec_t tail_exec;    // the tail alone (slow head + depth steps + commit) as run after a prefill
@@ -361,12 +364,17 @@ int run_decode_frame(SmolttsSession* s, hipStream_t st) {
 // Slot / last-row lists of a prefill call -> device, through the session's pinned staging buffer.  Only the previous
 // upload is waited for (an event), never the stream: a serving loop calls this while earlier frames are still running.
 int stage_upload(SmolttsSession* s, const int32_t* slots_host, const int32_t* last_row_host, int n_slots, hipStream_t st) {
-  if (s->stage_ev_live) ST_CHECK_HIP(hipEventSynchronize(s->stage_ev));
-  for (int i = 0; i < n_slots; ++i) { s->h_stage[i] = slots_host[i]; s->h_stage[s->B + i] = last_row_host[i]; }
-  ST_CHECK_HIP(hipMemcpyAsync(s->stage_slots, s->h_stage, sizeof(int) * n_slots, hipMemcpyHostToDevice, st));
-  ST_CHECK_HIP(hipMemcpyAsync(s->stage_last, s->h_stage + s->B, sizeof(int) * n_slots, hipMemcpyHostToDevice, st));
-  ST_CHECK_HIP(hipEventRecord(s->stage_ev, st));
-  s->stage_ev_live = true;
+  // a ring of pinned areas: the host only waits when STAGE_RING uploads are still queued behind other work on `st`
+  // (a serving loop uploads while a tick of frame graphs is pending; waiting for the previous upload would stall it)
+  const int k = s->stage_next;
+  s->stage_next = (k + 1) % STAGE_RING;
+  if (s->stage_ev_live[k]) ST_CHECK_HIP(hipEventSynchronize(s->stage_ev[k]));
+  int* h = s->h_stage + (size_t)k * 2 * s->B;
+  for (int i = 0; i < n_slots; ++i) { h[i] = slots_host[i]; h[s->B + i] = last_row_host[i]; }
+  ST_CHECK_HIP(hipMemcpyAsync(s->stage_slots, h, sizeof(int) * n_slots, hipMemcpyHostToDevice, st));
+  ST_CHECK_HIP(hipMemcpyAsync(s->stage_last, h + s->B, sizeof(int) * n_slots, hipMemcpyHostToDevice, st));
+  ST_CHECK_HIP(hipEventRecord(s->stage_ev[k], st));
+  s->stage_ev_live[k] = true;
   return SMOLTTS_OK;
 }
 
@@ -497,22 +505,26 @@ int smoltts_session_create(SmolttsEngine* e, void* slab_dev, size_t slab_bytes, 
   s->e = e; s->B = max_batch; s->max_seq = max_seq; s->max_rows = max_rows; s->max_frames = max_frames;
   size_t total = 0;
   carve(s, (char*)slab_dev, &total);
-  if (hipHostMalloc((void**)&s->h_stage, sizeof(int) * 2 * max_batch, hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc((void**)&s->h_stage, sizeof(int) * 2 * max_batch * STAGE_RING, hipHostMallocDefault) != hipSuccess) {
     delete s;
     set_error("session_create: hipHostMalloc failed");
     return SMOLTTS_E_HIP;
   }
-  if (hipEventCreateWithFlags(&s->stage_ev, hipEventDisableTiming) != hipSuccess) {
-    (void)hipHostFree(s->h_stage);
-    delete s;
-    set_error("session_create: hipEventCreate failed");
-    return SMOLTTS_E_HIP;
+  for (int k = 0; k < STAGE_RING; ++k) {
+    if (hipEventCreateWithFlags(&s->stage_ev[k], hipEventDisableTiming) != hipSuccess) {
+      for (int j = 0; j < k; ++j) (void)hipEventDestroy(s->stage_ev[j]);
+      (void)hipHostFree(s->h_stage);
+      delete s;
+      set_error("session_create: hipEventCreate failed");
+      return SMOLTTS_E_HIP;
+    }
   }
   hipLaunchKernelGGL(init_state_kernel, dim3((max_batch + 63) / 64), dim3(64), 0, 0, max_batch, e->cfg.n_fast, s->iota,
                      s->fastpos, s->pos, s->frames, s->done, s->mask, s->margin, s->cur_col, s->new_col);
   hipError_t err = hipGetLastError();
   if (err == hipSuccess) err = hipStreamSynchronize(0);
   if (err != hipSuccess) {
+    for (int k = 0; k < STAGE_RING; ++k) (void)hipEventDestroy(s->stage_ev[k]);
     (void)hipHostFree(s->h_stage);
     delete s;
     set_error("session_create: init kernel failed: %s", hipGetErrorString(err));
@@ -525,7 +537,8 @@ int smoltts_session_create(SmolttsEngine* e, void* slab_dev, size_t slab_bytes, 
 void smoltts_session_destroy(SmolttsSession* s) {
   if (!s) return;
   drop_graphs(s);
-  if (s->stage_ev) (void)hipEventDestroy(s->stage_ev);
+  for (int k = 0; k < STAGE_RING; ++k)
+    if (s->stage_ev[k]) (void)hipEventDestroy(s->stage_ev[k]);
   if (s->h_stage) (void)hipHostFree(s->h_stage);
   delete s;
 }

@@ -185,6 +185,34 @@ def _require_gpu() -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
+_UPLOAD_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def upload(arrays: Sequence[np.ndarray], device: torch.device) -> List[torch.Tensor]:
+    """Host arrays -> device tensors usable on the current stream, without waiting for the work already queued on it.
+    A plain ``tensor.to(device)`` from pageable memory is stream-ordered *and* blocks the host, i.e. it waits for everything
+    the stream still has to do (a serving loop has a tick of frame graphs pending there); here the copies leave pinned memory on
+    a side stream that is otherwise idle, and the current stream merely waits for their event."""
+    cur = torch.cuda.current_stream(device)
+    up = _UPLOAD_STREAMS.get(device.index)
+    if up is None:
+        up = _UPLOAD_STREAMS[device.index] = torch.cuda.Stream(device)
+        # torch caches pinned blocks per power-of-two size class, and the first block of a class costs a hipHostMalloc (ms):
+        # take a few of every class up to 1 MiB now, so that no request pays for one later
+        warm = [[torch.empty(1 << k, dtype=torch.uint8).pin_memory() for _ in range(4)] for k in range(8, 21)]
+        del warm
+    outs = []
+    with torch.cuda.stream(up):
+        for a in arrays:
+            t = torch.from_numpy(np.ascontiguousarray(a)).pin_memory().to(device, non_blocking=True)
+            t.record_stream(cur)  # allocated under the side stream, consumed on the current one
+            outs.append(t)
+        ev = torch.cuda.Event()
+        ev.record(up)
+    cur.wait_event(ev)
+    return outs
+
+
 def current_stream_ptr() -> int:
     return int(torch.cuda.current_stream().cuda_stream)
 
@@ -341,9 +369,7 @@ class LMSession:
         if n > self.max_rows:
             raise SmolttsError(f"{n} prompt rows exceed the session's max_rows={self.max_rows}")
         dev = self.engine.device
-        grid_d = torch.from_numpy(np.concatenate(cols)).to(dev)
-        rslot_d = torch.from_numpy(np.concatenate(rslot)).to(dev)
-        rpos_d = torch.from_numpy(np.concatenate(rpos)).to(dev)
+        grid_d, rslot_d, rpos_d = upload([np.concatenate(cols), np.concatenate(rslot), np.concatenate(rpos)], dev)
         slots_h = (C.c_int32 * len(slots))(*slots)
         last_h = (C.c_int32 * len(slots))(*last)
         self._keep = (grid_d, rslot_d, rpos_d)  # alive until the stream has consumed them

@@ -44,8 +44,15 @@ class _Request:
     closed: bool = False  # the end marker (None or an exception) has been queued
 
 
+@dataclass
+class _CodecJob:
+    req: _Request
+    cols: np.ndarray  # (F, n_codebooks) int32 audio codes of the complete utterance
+    done: int = 0     # frames already handed to the codec
+
+
 class BatchScheduler:
-    CODEC_BATCH, CODEC_CHUNK = 8, 64
+    CODEC_BATCH, CODEC_CHUNK, CODEC_WAIT = 16, 64, 32  # slots, frames per slot and pass, LM frames a pass may wait for company
 
     def __init__(self, tts, max_batch: int = 32, frames_per_tick: int = 4, generation_settings=None, max_prompt_rows: int = 4096,
                  prefill_chunk: Optional[int] = 128):
@@ -69,15 +76,19 @@ class BatchScheduler:
         self._active: Dict[int, _Request] = {}
         self._free: List[int] = list(range(max_batch))
         self._stop = threading.Event()
-        self._finished: List[_Request] = []     # complete blocking utterances waiting for their (batched) codec pass
-        self._finished_age = 0
-        self._batch_codec = None                # one multi-slot codec session for those passes
+        self._finished: List[_Request] = []     # complete blocking utterances waiting for a codec slot
+        self._batch_codec = None                # codec session of the blocking requests: CODEC_BATCH slots, one utterance each
+        self._codec_jobs: List[Optional[_CodecJob]] = [None] * self.CODEC_BATCH
+        self._codec_fresh: List[int] = []       # slots whose utterance has not been through a pass yet (stream restart due)
+        self._codec_slot_age = [0] * self.CODEC_BATCH  # passes a slot has seen since its last restart
+        self._codec_wait = 0                    # ticks since the last pass while work was waiting
         self._stream_codec = None               # codec session whose slot b carries the stream of LM slot b (streaming requests)
         self._codec_age = [0] * max_batch       # codec passes each of its slots has seen since that slot's last reset
         self._deliveries: List[tuple] = []      # (event, pcm on the device, [(request, first sample, n samples, last?)]) in order
         self._snaps: List[tuple] = []           # snapshots of the output ring the host has not looked at yet (oldest first)
         self._tick_no = 0                       # ticks queued so far
         self._counts = {"completed": 0, "cancelled": 0, "failed": 0, "frames_delivered": 0}
+        self._gpu_wait_s = 0.0                  # time the worker spent waiting for the GPU (small => the host is the limit)
         self._t0 = time.time()
         self._thread = threading.Thread(target=self._run, name="smoltts-scheduler", daemon=True)
         self._thread.start()
@@ -194,7 +205,10 @@ class BatchScheduler:
                     self._codec_age[b] = 0
             for b in range(self.B):
                 self._codec_age[b] += 1
-            idx = (torch.from_numpy(f0).cuda()[:, None] + torch.arange(self.tick, device="cuda")[None]).clamp_(max=self.max_frames - 1)
+            from ..engine import upload
+
+            f0_d, = upload([f0], self.session.engine.device)
+            idx = (f0_d[:, None] + torch.arange(self.tick, device="cuda")[None]).clamp_(max=self.max_frames - 1)
             nq = self.tts.config.num_codebooks
             chunk = s.codes[torch.arange(self.B, device="cuda")[:, None], idx][:, :, -nq:].contiguous()
             pcm = torch.empty(self.B, self.tick * 1920, dtype=torch.float32, device="cuda")
@@ -210,14 +224,26 @@ class BatchScheduler:
         torch = self._torch
         while len(self._snaps) > keep:
             codes_d, n_d, done_d, ev, tick_no, pcm_d = self._snaps.pop(0)
+            # the host waits for the snapshot, then copies on the copy stream: a device-side wait would park a blocked barrier
+            # packet in a second hardware queue for the whole tick, and the frame graphs' dependent launches get slower for it
+            self._wait_event(ev)
             with torch.cuda.stream(self._copy_stream):
-                self._copy_stream.wait_event(ev)
                 codes = codes_d.to("cpu", non_blocking=True)
                 n_frames = n_d.to("cpu", non_blocking=True)
                 done = done_d.to("cpu", non_blocking=True)
                 pcm = pcm_d.to("cpu", non_blocking=True) if pcm_d is not None else None
-            self._copy_stream.synchronize()
+            self._sync_copies()
             self._drain(codes.numpy(), n_frames.numpy(), done.numpy(), tick_no, None if pcm is None else pcm.numpy())
+
+    def _wait_event(self, ev) -> None:
+        t = time.perf_counter()
+        ev.synchronize()
+        self._gpu_wait_s += time.perf_counter() - t
+
+    def _sync_copies(self) -> None:
+        t = time.perf_counter()
+        self._copy_stream.synchronize()
+        self._gpu_wait_s += time.perf_counter() - t
 
     def _drain(self, codes, n_frames, done, tick_no: int, pcm) -> None:
         nq = self.tts.config.num_codebooks
@@ -260,52 +286,83 @@ class BatchScheduler:
                 self._finished.append(r)
 
     # ------------------------------------------------------------------ worker: codec passes and delivery
-    def _queue_codec(self, reqs, cols_list, sess, last) -> None:
-        """Queue the codec over the given utterances (one slot each, padded to the longest) on the compute stream; the PCM
-        is fetched by _deliver once the event behind the pass has fired."""
-        torch = self._torch
-        nq = cols_list[0].shape[1]
-        F = max(c.shape[0] for c in cols_list)
-        grid = np.zeros((len(reqs), F, nq), np.int32)
-        for b, c in enumerate(cols_list):
-            grid[b, : c.shape[0]] = c
-        codes = torch.from_numpy(grid).cuda()
-        pcm = torch.empty(len(reqs), F * 1920, dtype=torch.float32, device="cuda")
-        for f0 in range(0, F, sess.chunk):
-            sess.decode_chunk(codes, f0, min(sess.chunk, F - f0), pcm, code_offset=0)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        self._deliveries.append((ev, pcm, [(r, b, c.shape[0] * 1920, fin) for b, (r, c, fin) in enumerate(zip(reqs, cols_list, last))]))
+    def _codec_backlog(self) -> bool:
+        return bool(self._finished) or any(j is not None for j in self._codec_jobs)
 
     def _decode_finished(self, force: bool) -> None:
-        """Codec pass over up to CODEC_BATCH complete blocking utterances (each in its own slot from position 0, the shorter
-        ones padded at the end: the decoder is causal, so the padding cannot reach their samples).  Queued when enough
-        utterances wait, when they have waited two ticks, or when nothing else is going on."""
-        if not self._finished:
-            return
-        self._finished_age += 1
-        if not (force or len(self._finished) >= self.CODEC_BATCH or self._finished_age >= 2):
-            return
-        from ..engine import MimiSession
+        """Codec work of the blocking requests: a pool of CODEC_BATCH codec slots, each decoding one complete utterance
+        CODEC_CHUNK frames per pass; a slot whose utterance is through takes the next one waiting (its stream restarts at
+        position 0), so a pass stays as wide as the backlog allows instead of narrowing towards the longest utterance.  A pass
+        is queued when the pool is full, when work has waited long enough — CODEC_WAIT frames of LM ticks while the LM batch is busy (wide
+        passes cost half as much per frame as narrow ones), one tick otherwise — or when nothing else is going on; its PCM
+        goes out chunk by chunk through _deliver."""
+        from ..engine import MimiSession, upload
 
-        if self._batch_codec is None:
-            self._batch_codec = MimiSession(self.tts.codec, max_batch=self.CODEC_BATCH, max_chunk_frames=self.CODEC_CHUNK)
+        torch = self._torch
+        jobs = self._codec_jobs
+        for b, j in enumerate(jobs):  # clients that went away
+            if j is not None and j.req.cancelled:
+                self._end(j.req)
+                jobs[b] = None
         nq = self.tts.config.num_codebooks
-        for r in self._finished:
+        while self._finished and None in jobs:
+            r = self._finished.pop(0)
             if r.cancelled:
                 self._end(r)
-        self._finished = [r for r in self._finished if not r.cancelled]
-        while self._finished:
-            batch, self._finished = self._finished[: self.CODEC_BATCH], self._finished[self.CODEC_BATCH:]
-            cols = [np.concatenate(r.pending) if r.pending else np.zeros((0, nq), np.int32) for r in batch]
-            for r in batch:
-                r.pending = []
-            if max(c.shape[0] for c in cols) == 0:
-                self._deliveries.append((None, None, [(r, 0, 0, True) for r in batch]))
                 continue
+            cols = np.concatenate(r.pending) if r.pending else np.zeros((0, nq), np.int32)
+            r.pending = []
+            if cols.shape[0] == 0:  # nothing to decode (every frame was non-semantic): just close the response, in order
+                self._deliveries.append((None, None, [(r, 0, 0, True)]))
+                continue
+            b = jobs.index(None)
+            jobs[b] = _CodecJob(r, cols)
+            self._codec_fresh.append(b)
+        occupied = [b for b, j in enumerate(jobs) if j is not None]
+        if not occupied:
+            self._codec_wait = 0
+            return
+        self._codec_wait += 1
+        busy = (not self._pending.empty()) or 4 * len(self._active) >= 3 * self.B
+        if not (force or len(occupied) == len(jobs) or self._codec_wait >= (max(1, self.CODEC_WAIT // self.tick) if busy else 1)):
+            return
+        self._codec_wait = 0
+        if self._batch_codec is None:
+            self._batch_codec = MimiSession(self.tts.codec, max_batch=self.CODEC_BATCH, max_chunk_frames=self.CODEC_CHUNK)
             self._batch_codec.reset()
-            self._queue_codec(batch, cols, self._batch_codec, last=[True] * len(batch))
-        self._finished_age = 0
+        sess = self._batch_codec
+        m = occupied[-1] + 1  # the pass runs over slots 0..m-1; a hole among them decodes zeros that nobody reads
+        n = [min(self.CODEC_CHUNK, jobs[b].cols.shape[0] - jobs[b].done) if jobs[b] is not None else 0 for b in range(m)]
+        nmax = max(n)
+        # restart the streams of new utterances, and of holes before their position would reach the codec's capacity
+        cap = int(self.tts.codec.c_cfg.max_positions)
+        restart = sorted(set(self._codec_fresh) | {b for b in range(m) if jobs[b] is None and (self._codec_slot_age[b] + 2) * 2 * self.CODEC_CHUNK > cap})
+        if restart:
+            sess.reset_slots(restart)
+            for b in restart:
+                self._codec_slot_age[b] = 0
+        self._codec_fresh = []
+        grid = np.zeros((m, nmax, nq), np.int32)
+        for b in range(m):
+            if n[b]:
+                grid[b, : n[b]] = jobs[b].cols[jobs[b].done: jobs[b].done + n[b]]
+        codes, = upload([grid], self.session.engine.device)
+        pcm = torch.empty(m, nmax * 1920, dtype=torch.float32, device="cuda")
+        sess.decode_chunk(codes, 0, nmax, pcm, code_offset=0)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        items = []
+        for b in range(m):
+            self._codec_slot_age[b] += 1
+            if not n[b]:
+                continue
+            j = jobs[b]
+            j.done += n[b]
+            fin = j.done >= j.cols.shape[0]
+            items.append((j.req, b, n[b] * 1920, fin))
+            if fin:
+                jobs[b] = None
+        self._deliveries.append((ev, pcm, items))
 
     def _deliver(self, wait: bool) -> None:
         """Hand finished codec passes to their requests, in order; ``wait``: block on the oldest one."""
@@ -315,10 +372,10 @@ class BatchScheduler:
             if ev is not None:
                 if not (wait or ev.query()):
                     return
+                self._wait_event(ev)
                 with torch.cuda.stream(self._copy_stream):
-                    self._copy_stream.wait_event(ev)
                     host = pcm.to("cpu", non_blocking=True)
-                self._copy_stream.synchronize()
+                self._sync_copies()
                 host = host.numpy()
             self._deliveries.pop(0)
             for r, b, n, fin in items:
@@ -341,8 +398,8 @@ class BatchScheduler:
                     if not self._active:
                         self._consume_snapshots(keep=0)
                         self._decode_finished(force=True)
-                        if self._deliveries:
-                            self._deliver(wait=True)
+                        if self._deliveries or self._codec_backlog():
+                            self._deliver(wait=not self._codec_backlog())  # keep the passes coming while there is codec work
                             continue
                         try:
                             self._pending.put(self._pending.get(timeout=0.05))  # idle: wait for work without spinning
@@ -372,12 +429,13 @@ class BatchScheduler:
         slots in use, queue length."""
         up = time.time() - self._t0
         return dict(self._counts, ticks=self._tick_no, frames_per_tick=self.tick, slots=self.B, active=len(self._active),
-                    queued=self._pending.qsize(), awaiting_codec=len(self._finished), uptime_s=up,
+                    queued=self._pending.qsize(), awaiting_codec=len(self._finished) + sum(1 for j in self._codec_jobs if j is not None), uptime_s=up, gpu_wait_s=self._gpu_wait_s,
                     delivered_frames_per_s=self._counts["frames_delivered"] / up if up > 0 else 0.0)
 
     def _fail_all(self, e: Exception) -> None:
-        for r in list(self._active.values()) + self._finished:
+        for r in list(self._active.values()) + self._finished + [j.req for j in self._codec_jobs if j is not None]:
             self._end(r, e)
+        self._codec_jobs = [None] * len(self._codec_jobs)
         for _, _, items in self._deliveries:
             for r, _, _, _ in items:
                 self._end(r, e)

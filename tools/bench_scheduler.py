@@ -36,6 +36,10 @@ def main():
         sched = GpuPool(functools.partial(synthetic_scheduler, "smoltts_byte_150m", 0, 0, 32, tick, 400), devices=[0] * n_pool)
     else:
         cfg = named_config("smoltts_byte_150m")
+        import os
+        if os.environ.get("CODEC"):  # experiment: CODEC_BATCH,CODEC_CHUNK,CODEC_WAIT of the blocking codec passes
+            BatchScheduler.CODEC_BATCH, BatchScheduler.CODEC_CHUNK, BatchScheduler.CODEC_WAIT = (int(x) for x in os.environ["CODEC"].split(","))
+        cfg.max_seq_len = int(os.environ.get("MAX_SEQ", cfg.max_seq_len))  # experiment: the session's KV stride
         tts = SmolTTS(state=synthetic_lm_state(cfg, seed=0), config=cfg, mimi_state=synthetic_mimi_state(seed=0))
         sched = BatchScheduler(tts, max_batch=32, frames_per_tick=tick, generation_settings=GenerationSettings.greedy(max_new_tokens=400))
     for _ in range(max(n_pool, 1) * 2):
@@ -61,6 +65,53 @@ def main():
             samples[i] = sched.synthesize(texts[i], "heart", max_new_tokens=int(budgets[i])).shape[0]
 
 
+    st0 = sched.stats() if not n_pool else {}
+    if not n_pool:
+        import torch as _t
+        from smoltts_amd.engine import MimiSession
+        _codec_ev = []
+        _orig_dc = MimiSession.decode_chunk
+
+        def _dc(self, *a, **k):
+            e0, e1 = _t.cuda.Event(enable_timing=True), _t.cuda.Event(enable_timing=True)
+            e0.record()
+            try:
+                return _orig_dc(self, *a, **k)
+            finally:
+                e1.record()
+                _codec_ev.append((e0, e1))
+        MimiSession.decode_chunk = _dc
+    phase = {}
+    if not n_pool:  # host time of the worker loop by phase
+        def timed(name):
+            f = getattr(sched, name)
+
+            def g(*a, **k):
+                t = time.perf_counter()
+                try:
+                    return f(*a, **k)
+                finally:
+                    phase[name] = phase.get(name, 0.0) + time.perf_counter() - t
+            setattr(sched, name, g)
+        import torch
+        gpu_ev = {"decode": [], "prefill": [], "codec": []}
+
+        def gpu_timed(obj, name, key):
+            f = getattr(obj, name)
+
+            def g(*a, **k):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                try:
+                    return f(*a, **k)
+                finally:
+                    e1.record()
+                    gpu_ev[key].append((e0, e1))
+            setattr(obj, name, g)
+        gpu_timed(sched.session, "decode", "decode")
+        gpu_timed(sched.session, "prefill", "prefill")
+        for name in ("_admit", "_tick_and_snapshot", "_decode_finished", "_deliver", "_consume_snapshots", "_drain"):
+            timed(name)
     t0 = time.perf_counter()
     threads = [threading.Thread(target=worker, args=(i,)) for i in range(n_req)]
     for t in threads:
@@ -72,6 +123,14 @@ def main():
     print(f"{n_req} {'streaming' if streaming else 'blocking'} requests, {frames} frames of audio in {dt:.2f} s -> {frames / dt:.0f} frames/s "
           f"({frames / dt / 12.5:.0f}x real time), tick {tick}" + (f", pool of {n_pool} worker processes" if n_pool else "")
           + (f"; time to first chunk p50 {np.median(first_chunk_ms):.1f} ms (includes queueing for a slot)" if first_chunk_ms else ""))
+    if not n_pool:
+        st1 = sched.stats()
+        ticks = st1["ticks"] - st0["ticks"]
+        torch.cuda.synchronize()
+        gpu_ev["codec"] = _codec_ev
+        print("  GPU time (s): " + ", ".join(f"{k} {sum(a.elapsed_time(b) for a, b in v) / 1e3:.2f} ({len(v)} calls)" for k, v in gpu_ev.items() if v))
+        print("  host time by phase (s): " + ", ".join(f"{k} {v:.2f}" for k, v in sorted(phase.items(), key=lambda kv: -kv[1])))
+        print(f"  worker: {ticks} ticks ({ticks * tick * 32} slot-frames for {frames} delivered), waited for the GPU {st1['gpu_wait_s'] - st0['gpu_wait_s']:.2f} s of {dt:.2f} s")
     sched.close()
 
 
