@@ -88,3 +88,39 @@ def test_scheduler_survives_churn_and_stays_exact():
         assert float(np.sqrt(np.mean((got - w) ** 2))) <= 1e-6
         n_checked += 1
     assert n_checked >= 80
+
+
+def test_blocking_codec_pool_refills_and_stays_exact():
+    """The codec slot pool of the blocking requests with a tiny geometry (3 slots, 4 frames per pass): utterances need many
+    passes, finish at different times, leave holes and are replaced mid-stream; the audio must not change."""
+    from smoltts_amd import SmolTTS
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+    from smoltts_amd.config import GenerationSettings
+    from smoltts_amd.server.scheduler import BatchScheduler
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+
+    class SmallPool(BatchScheduler):
+        CODEC_BATCH, CODEC_CHUNK, CODEC_WAIT = 3, 4, 2
+
+    cfg = named_config("tiny")
+    tts = SmolTTS(state=synthetic_lm_state(cfg, seed=21), config=cfg, mimi_state=synthetic_mimi_state(seed=5))
+    budgets = [23, 2, 9, 17, 1, 30, 5, 12, 26, 3, 8, 21]
+    texts = [f"utterance number {i} " + "x" * (i % 5) for i in range(len(budgets))]
+    want = [tts(t, "sky", generation_settings=GenerationSettings.greedy(max_new_tokens=n)) for t, n in zip(texts, budgets)]
+    sched = SmallPool(tts, max_batch=4, frames_per_tick=3, generation_settings=GenerationSettings.greedy(max_new_tokens=32))
+    got = [None] * len(budgets)
+
+    def client(i):
+        got[i] = sched.synthesize(texts[i], "sky", max_new_tokens=budgets[i])
+
+    threads = [threading.Thread(target=client, args=(i,)) for i in range(len(budgets))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    st = sched.stats()
+    sched.close()
+    assert st["completed"] == len(budgets) and st["failed"] == 0 and st["awaiting_codec"] == 0
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g is not None and g.shape == w.shape, (i, None if g is None else g.shape, w.shape)
+        assert float(np.sqrt(np.mean((g - w) ** 2))) <= 1e-6, i
