@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the first-audio-chunk latency measurement")
     ap.add_argument("--no-mimi", action="store_true", help="diagnostic only: skip the Mimi decode (the result line is then not the metric)")
     ap.add_argument("--overlap-mimi", action="store_true", help="run the Mimi chunk decode on its own stream behind an event (measured: no gain, the many-workgroup Mimi kernels delay the latency-bound frame graphs)")
+    ap.add_argument("--overlap-wait", default="device", choices=["device", "host"], help="with --overlap-mimi: how the Mimi stream learns that a chunk's codes are ready: a device-side wait_event (parks a blocked barrier packet in the second queue), or the host waits for the event and only then launches (one chunk behind the frame graphs)")
     ap.add_argument("--mimi-cus", type=int, default=0, help="with --overlap-mimi: restrict the Mimi stream to this many CUs (hipExtStreamCreateWithCUMask)")
     ap.add_argument("--cu-pattern", default="low", choices=["low", "xcd"], help="which mask bits: the N lowest, or N/32 whole XCDs (bit i -> XCD i mod 8)")
     ap.add_argument("--lm-complement", action="store_true", help="restrict the frame-graph stream to the CUs the Mimi stream does not use")
@@ -182,13 +183,27 @@ def main():
             streams = [masked_stream([not b for b in bits], -1) for _ in range(S)]
         log(f"CU masks: Mimi stream on {sum(bits)} of {n_cu} CUs ({args.cu_pattern}); frame graphs on {'the complement' if args.lm_complement else 'all'}")
 
+    host_wait = args.overlap_mimi and args.overlap_wait == "host" and not args.no_mimi
+    behind = [None] * S  # host-wait mode: (event, chunk index) of the chunk whose Mimi decode has not been launched yet
+
+    def flush(j):
+        if behind[j] is not None:
+            ev, i = behind[j]
+            ev.synchronize()  # the codes of chunk i are there; the frame graphs of chunk i + 1 are already queued
+            with torch.cuda.stream(mimi_streams[j]):
+                msessions[j].decode_chunk(sessions[j].codes, i * CH, CH, pcms[j], code_offset=1)
+            behind[j] = None
+
     def step(i):
         for j in range(S):
             with torch.cuda.stream(streams[j]):
                 sessions[j].decode(CH)
                 ev = torch.cuda.Event()
                 ev.record(streams[j])
-            if not args.no_mimi:
+            if host_wait:
+                flush(j)
+                behind[j] = (ev, i)
+            elif not args.no_mimi:
                 with torch.cuda.stream(mimi_streams[j] if args.overlap_mimi else streams[j]):
                     if args.overlap_mimi:
                         mimi_streams[j].wait_event(ev)
@@ -207,12 +222,16 @@ def main():
             msessions[j].reset()
     for i in range(W):
         step(i)
+    for j in range(S):
+        flush(j)
     torch.cuda.synchronize()
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(W, W + K):
         step(i)
+    for j in range(S):
+        flush(j)
     torch.cuda.synchronize()
     parallel.barrier()
     torch.cuda.synchronize()
