@@ -466,8 +466,12 @@ __global__ __launch_bounds__(256) void gemm3_rows_kernel(Gemm3Dev p) {
 template <int EPI, bool W8>
 static int launch3_rows(const Gemm3Dev& d, hipStream_t stream) {
   const int ntiles = (d.N + 15) / 16;
-  const int NTW = ntiles >= 16 ? 4 : (ntiles >= 8 ? 2 : 1);
-  const dim3 grid((ntiles + 4 * NTW - 1) / (4 * NTW), (d.M + 63) / 64);
+  int NTW = ntiles >= 16 ? 4 : (ntiles >= 8 ? 2 : 1);
+  // narrow outputs over few row blocks (wo / w2 of a 3.5k-row prompt batch: 3 x 56 workgroups) leave CUs idle: halve the
+  // column tile until the grid covers the chip
+  const int row_blocks = (d.M + 63) / 64;
+  while (NTW > 1 && ((ntiles + 4 * NTW - 1) / (4 * NTW)) * row_blocks < 256) NTW >>= 1;
+  const dim3 grid((ntiles + 4 * NTW - 1) / (4 * NTW), row_blocks);
   ST_REQUIRE(grid.y <= 65535, SMOLTTS_E_INVALID, "gemm3: M=%d too large for one launch", d.M);
   if (NTW == 4) hipLaunchKernelGGL((gemm3_rows_kernel<4, EPI, W8>), grid, dim3(256), 0, stream, d);
   else if (NTW == 2) hipLaunchKernelGGL((gemm3_rows_kernel<2, EPI, W8>), grid, dim3(256), 0, stream, d);

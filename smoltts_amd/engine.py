@@ -188,19 +188,33 @@ def _require_gpu() -> torch.device:
 _UPLOAD_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
 
 
+def upload_stream(device: torch.device) -> "torch.cuda.Stream":
+    """The side stream of ``upload`` for this device, created (and the pinned allocator warmed) on first use; engines call
+    this when they are built so that no request pays for it."""
+    up = _UPLOAD_STREAMS.get(device.index)
+    if up is None:
+        up = _UPLOAD_STREAMS[device.index] = torch.cuda.Stream(device)
+        # torch caches pinned blocks per power-of-two size class, and the first block of a class costs a hipHostMalloc (ms):
+        # take a few of every class up to 1 MiB now
+        warm = [[torch.empty(1 << k, dtype=torch.uint8).pin_memory() for _ in range(4)] for k in range(8, 21)]
+        # ... and put one copy and one event through the stream: its hardware queue is only created by the first submission
+        with torch.cuda.stream(up):
+            warm[0][0].to(device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(up)
+        torch.cuda.current_stream(device).wait_event(ev)
+        up.synchronize()
+        del warm
+    return up
+
+
 def upload(arrays: Sequence[np.ndarray], device: torch.device) -> List[torch.Tensor]:
     """Host arrays -> device tensors usable on the current stream, without waiting for the work already queued on it.
     A plain ``tensor.to(device)`` from pageable memory is stream-ordered *and* blocks the host, i.e. it waits for everything
     the stream still has to do (a serving loop has a tick of frame graphs pending there); here the copies leave pinned memory on
     a side stream that is otherwise idle, and the current stream merely waits for their event."""
     cur = torch.cuda.current_stream(device)
-    up = _UPLOAD_STREAMS.get(device.index)
-    if up is None:
-        up = _UPLOAD_STREAMS[device.index] = torch.cuda.Stream(device)
-        # torch caches pinned blocks per power-of-two size class, and the first block of a class costs a hipHostMalloc (ms):
-        # take a few of every class up to 1 MiB now, so that no request pays for one later
-        warm = [[torch.empty(1 << k, dtype=torch.uint8).pin_memory() for _ in range(4)] for k in range(8, 21)]
-        del warm
+    up = upload_stream(device)
     outs = []
     with torch.cuda.stream(up):
         for a in arrays:
@@ -264,6 +278,7 @@ class LMEngine:
         cfg.validate_for_engine()
         self.lib = load_library()
         self.device = _require_gpu()
+        upload_stream(self.device)
         self.cfg, self.token_config = cfg, token_config
         self.numerics = numerics or NumericsMode.torch_reference()
         if arena is None:
