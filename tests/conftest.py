@@ -15,8 +15,11 @@ GOLDEN = ROOT / "tests" / "golden"
 if sys.platform == "linux":
     from multiprocessing import forkserver as _forkserver
 
-    _forkserver.set_forkserver_preload([])
-    _forkserver.ensure_running()
+    try:
+        _forkserver.set_forkserver_preload([])
+        _forkserver.ensure_running()
+    except Exception:  # no fork server here: the pool starts one on demand instead
+        pass
 
 
 def pytest_configure(config):
