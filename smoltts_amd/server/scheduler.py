@@ -88,6 +88,8 @@ class BatchScheduler:
         self._snaps: List[tuple] = []           # snapshots of the output ring the host has not looked at yet (oldest first)
         self._tick_no = 0                       # ticks queued so far
         self._counts = {"completed": 0, "cancelled": 0, "failed": 0, "frames_delivered": 0}
+        self._dead: Optional[Exception] = None  # why the worker stopped
+        self._held: Optional[_Request] = None   # next in line, waiting for room in a prefill call
         self._gpu_wait_s = 0.0                  # time the worker spent waiting for the GPU (small => the host is the limit)
         self._t0 = time.time()
         self._thread = threading.Thread(target=self._run, name="smoltts-scheduler", daemon=True)
@@ -95,8 +97,12 @@ class BatchScheduler:
 
     # ------------------------------------------------------------------ client side
     def submit(self, text: str, voice: str = "heart", stream: bool = False, max_new_tokens: Optional[int] = None) -> _Request:
+        if self._dead is not None:  # the worker is gone (engine failure or close): nobody would ever answer
+            raise RuntimeError(f"scheduler is not running: {self._dead}")
         req = _Request(text, voice, stream, min(max_new_tokens or self.settings.max_new_tokens, self.settings.max_new_tokens))
         self._pending.put(req)
+        if self._dead is not None:  # lost the race with a failing worker: answer it ourselves
+            self._end(req, RuntimeError(f"scheduler is not running: {self._dead}"))
         return req
 
     def synthesize(self, text: str, voice: str = "heart", max_new_tokens: Optional[int] = None) -> np.ndarray:
@@ -137,34 +143,37 @@ class BatchScheduler:
     # ------------------------------------------------------------------ worker: admission
     def _admit(self) -> None:
         new: List[_Request] = []
-        while self._free and not self._pending.empty():
-            req = self._pending.get_nowait()
+        rows = 0  # prompt rows of the (first) prefill call of this admission; the session's workspace holds max_rows
+        while self._free and (self._held is not None or not self._pending.empty()):
+            req, self._held = (self._held, None) if self._held is not None else (self._pending.get_nowait(), None)
             if req.cancelled:
                 self._end(req)
                 continue
-            try:
-                req.prompt = self.tts._get_prompt(req.text, req.voice)
-                if req.prompt.shape[1] + req.max_new_tokens + 2 > self.session.max_seq:
-                    raise ValueError("prompt + max_new_tokens exceed max_seq_len")
-            except Exception as e:  # bad request: answer it, keep serving
-                self._end(req, e)
-                continue
+            if req.prompt is None:
+                try:
+                    req.prompt = self.tts._get_prompt(req.text, req.voice)
+                    if req.prompt.shape[1] + req.max_new_tokens + 2 > self.session.max_seq:
+                        raise ValueError("prompt + max_new_tokens exceed max_seq_len")
+                    if min(req.prompt.shape[1], self.prefill_chunk or req.prompt.shape[1]) > self.session.max_rows:
+                        raise ValueError("prompt exceeds the session's prefill workspace")
+                except Exception as e:  # bad request: answer it, keep serving
+                    self._end(req, e)
+                    continue
+            need = min(req.prompt.shape[1], self.prefill_chunk or req.prompt.shape[1])
+            if new and rows + need > self.session.max_rows:  # no room in this call: first in line next time
+                self._held = req
+                break
+            rows += need
             req.slot = self._free.pop(0)
             new.append(req)
         if not new:
             return
-        if self.prefill_chunk:
-            # long prompts (voice-clone speakers) enter in chunks; the slots already speaking get a tick in between
-            def between():
-                if self._active:
-                    self._tick_and_snapshot()
-                    self._consume_snapshots(keep=1)
-
-            self.session.prefill_chunked([r.prompt for r in new], slots=[r.slot for r in new], stop_on_eos=True,
-                                         chunk=self.prefill_chunk, between=between, defer_frame0=True)
-        else:
-            # frame 0 of the new slots comes out of the next tick's first frame (no separate tail for all slots)
-            self.session.prefill([r.prompt for r in new], slots=[r.slot for r in new], stop_on_eos=True, defer_frame0=True)
+        try:
+            self._prefill(new)
+        except Exception as e:  # these requests are in nobody's books yet: answer them here, then let the worker fail
+            for r in new:
+                self._end(r, e)
+            raise
         streams = [r.slot for r in new if r.stream]
         if streams:
             from ..engine import MimiSession
@@ -178,6 +187,20 @@ class BatchScheduler:
         for r in new:
             r.first_tick = self._tick_no
             self._active[r.slot] = r
+
+    def _prefill(self, new: List[_Request]) -> None:
+        if self.prefill_chunk:
+            # long prompts (voice-clone speakers) enter in chunks; the slots already speaking get a tick in between
+            def between():
+                if self._active:
+                    self._tick_and_snapshot()
+                    self._consume_snapshots(keep=1)
+
+            self.session.prefill_chunked([r.prompt for r in new], slots=[r.slot for r in new], stop_on_eos=True,
+                                         chunk=self.prefill_chunk, between=between, defer_frame0=True)
+        else:
+            # frame 0 of the new slots comes out of the next tick's first frame (no separate tail for all slots)
+            self.session.prefill([r.prompt for r in new], slots=[r.slot for r in new], stop_on_eos=True, defer_frame0=True)
 
     # ------------------------------------------------------------------ worker: ticks and snapshots
     def _tick_and_snapshot(self) -> None:
@@ -433,6 +456,10 @@ class BatchScheduler:
                     delivered_frames_per_s=self._counts["frames_delivered"] / up if up > 0 else 0.0)
 
     def _fail_all(self, e: Exception) -> None:
+        self._dead = e
+        if self._held is not None:
+            self._end(self._held, e)
+            self._held = None
         for r in list(self._active.values()) + self._finished + [j.req for j in self._codec_jobs if j is not None]:
             self._end(r, e)
         self._codec_jobs = [None] * len(self._codec_jobs)

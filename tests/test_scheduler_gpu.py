@@ -141,3 +141,40 @@ def test_scheduler_cancel_frees_the_slot_and_leaves_the_others_alone():
         assert st["frames_delivered"] >= (want_next.shape[0] + want_long.shape[0]) // 1920
     finally:
         sched.close()
+
+
+def test_scheduler_splits_admissions_that_exceed_the_prefill_workspace_and_fails_loudly():
+    """More prompt rows arriving at once than one prefill call can take are admitted over several calls, in order; an engine
+    failure during admission answers every request — also the ones being admitted at that moment — and later submits raise."""
+    from smoltts_amd import SmolTTS
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+    from smoltts_amd.config import GenerationSettings
+    from smoltts_amd.server.scheduler import BatchScheduler
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+
+    cfg = named_config("tiny")
+    tts = SmolTTS(state=synthetic_lm_state(cfg, seed=21), config=cfg, mimi_state=synthetic_mimi_state(seed=5))
+    gs = GenerationSettings.greedy(max_new_tokens=5)
+    texts = [f"request number {i}, some text" for i in range(8)]  # ~50 prompt columns each
+    want = [tts(t, "sky", generation_settings=gs) for t in texts]
+    sched = BatchScheduler(tts, max_batch=8, frames_per_tick=2, generation_settings=gs, max_prompt_rows=120, prefill_chunk=None)
+    reqs = [sched.submit(t, "sky") for t in texts]  # 8 x ~50 rows against a 120-row workspace: at most two per call
+    got = [np.concatenate(list(sched.iter_chunks(r)) or [np.zeros(0, np.float32)]) for r in reqs]
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g.shape == w.shape and float(np.sqrt(np.mean((g - w) ** 2))) <= 1e-6, i
+    with pytest.raises(ValueError, match="workspace"):
+        sched.synthesize("x" * 200)  # one prompt that no call can take: refused, the scheduler keeps serving
+    assert sched.synthesize(texts[0], "sky").shape == want[0].shape
+
+    def boom(*a, **k):
+        raise RuntimeError("injected engine failure")
+
+    sched.session.prefill = boom
+    victims = [sched.submit(t, "sky") for t in texts[:3]]
+    for r in victims:
+        with pytest.raises(RuntimeError, match="injected engine failure"):
+            list(sched.iter_chunks(r))
+    sched._thread.join(timeout=30)
+    with pytest.raises(RuntimeError, match="not running"):
+        sched.submit("anyone there?")
+    sched.close()

@@ -41,7 +41,8 @@ def main():
             BatchScheduler.CODEC_BATCH, BatchScheduler.CODEC_CHUNK, BatchScheduler.CODEC_WAIT = (int(x) for x in os.environ["CODEC"].split(","))
         cfg.max_seq_len = int(os.environ.get("MAX_SEQ", cfg.max_seq_len))  # experiment: the session's KV stride
         tts = SmolTTS(state=synthetic_lm_state(cfg, seed=0), config=cfg, mimi_state=synthetic_mimi_state(seed=0))
-        sched = BatchScheduler(tts, max_batch=32, frames_per_tick=tick, generation_settings=GenerationSettings.greedy(max_new_tokens=400))
+        slots = int(os.environ.get("SLOTS", 32))
+        sched = BatchScheduler(tts, max_batch=slots, frames_per_tick=tick, generation_settings=GenerationSettings.greedy(max_new_tokens=400))
     for _ in range(max(n_pool, 1) * 2):
         sched.synthesize("warm up", max_new_tokens=8)
     if streaming:
@@ -130,7 +131,7 @@ def main():
         gpu_ev["codec"] = _codec_ev
         print("  GPU time (s): " + ", ".join(f"{k} {sum(a.elapsed_time(b) for a, b in v) / 1e3:.2f} ({len(v)} calls)" for k, v in gpu_ev.items() if v))
         print("  host time by phase (s): " + ", ".join(f"{k} {v:.2f}" for k, v in sorted(phase.items(), key=lambda kv: -kv[1])))
-        print(f"  worker: {ticks} ticks ({ticks * tick * 32} slot-frames for {frames} delivered), waited for the GPU {st1['gpu_wait_s'] - st0['gpu_wait_s']:.2f} s of {dt:.2f} s")
+        print(f"  worker: {ticks} ticks ({ticks * tick * sched.B} slot-frames for {frames} delivered), waited for the GPU {st1['gpu_wait_s'] - st0['gpu_wait_s']:.2f} s of {dt:.2f} s")
     sched.close()
 
 
