@@ -35,10 +35,13 @@ class TTSCore:
         return 0
 
     def generate_audio(self, input_text: str, voice: Union[str, int], response_format: str = "wav_24000"):
-        if self.scheduler is not None:
-            pcm = self.scheduler.synthesize(input_text, str(voice))
-        else:
-            pcm = np.asarray(self.model(input_text, str(voice))).flatten()
+        try:
+            if self.scheduler is not None:
+                pcm = self.scheduler.synthesize(input_text, str(voice))
+            else:
+                pcm = np.asarray(self.model(input_text, str(voice))).flatten()
+        except ValueError as e:  # a request the engine refuses (e.g. a text too long for max_seq_len): the client's fault, not a 500
+            raise HTTPException(status_code=400, detail=str(e))
         return self.format_audio_chunk(pcm, response_format)
 
     def stream_audio(self, input_text: str, voice: Union[str, int]):

@@ -9,6 +9,8 @@ class _FakeTTS:
     sampling_rate = 24000
 
     def __call__(self, text, voice="heart"):
+        if len(text) > 1000:
+            raise ValueError("prompt + max_new_tokens exceed max_seq_len")
         return np.linspace(-0.5, 0.5, 1920 * max(1, len(text)), dtype=np.float32)
 
     def stream(self, text, voice="heart"):
@@ -43,6 +45,8 @@ def test_openai_speech_route(client):
     assert r.headers["content-disposition"] == 'attachment; filename="speech.wav"'
     assert r.content[:4] == b"RIFF" and len(r.content) == 44 + 2 * 1920 * 2
     assert client.post("/v1/audio/speech", json={"voice": "heart"}).status_code == 422          # missing input
+    r = client.post("/v1/audio/speech", json={"input": "x" * 2000})                               # refused by the engine
+    assert r.status_code == 400 and "max_seq_len" in r.json()["detail"]
     assert client.post("/v1/audio/speech", json={"input": "x", "response_format": "mp3"}).status_code == 422
 
 
