@@ -75,7 +75,7 @@ def _worker_main(device: str, factory: Callable[[], object], req_q, res_conn) ->
                 res_q.put((rid, "chunk", np.ascontiguousarray(chunk, dtype=np.float32)))
             res_q.put((rid, "end", None))
         except Exception as e:
-            res_q.put((rid, "error", f"{type(e).__name__}: {e}"))
+            res_q.put((rid, "error", (type(e).__name__, str(e))))
         finally:
             with lock:
                 live.pop(rid, None)
@@ -243,7 +243,8 @@ class GpuPool:
             elif kind == "end":
                 self._finish(req, None)
             elif kind == "error":
-                self._finish(req, RuntimeError(payload))
+                name, msg = payload  # a refused request (ValueError) stays one: the HTTP layer answers 400 for it, 500 for the rest
+                self._finish(req, ValueError(msg) if name == "ValueError" else RuntimeError(f"{name}: {msg}"))
 
     def _kill(self) -> None:
         for p in self._procs:

@@ -51,7 +51,7 @@ def test_pool_routes_relays_and_balances():
         assert pool.loads() == [0, 0] and pool.stats() == {"workers": 2, "alive": 2, "in_flight": [0, 0]}
         assert pool.synthesize("abcd", max_new_tokens=2).shape == (8,)
         # an error raised for one request reaches that client only
-        with pytest.raises(RuntimeError, match="bad request"):
+        with pytest.raises(ValueError, match="bad request"):  # the type survives the process boundary (HTTP 400, not 500)
             pool.synthesize("__raise__")
         assert pool.synthesize("ok").shape == (8,)
     finally:
