@@ -49,7 +49,7 @@ int smoltts_k_argmax(const float* logits_dev, int32_t n_rows, int32_t n_cols, in
 
 int smoltts_k_sample(const float* logits_dev, int32_t n_rows, int32_t n_cols, int64_t ld, float temp, float min_p, uint64_t seed,
                      int32_t frame_base, int32_t step, int32_t* ids_dev, void* stream) {
-  const SampleArgs sa{temp, min_p, seed, step, frame_base, nullptr};
+  const SampleArgs sa{temp, min_p, seed, step, frame_base, nullptr, nullptr};
   return launch_argmax(logits_dev, n_rows, n_cols, ld, ids_dev, 1, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, &sa,
                        (hipStream_t)stream);
 }

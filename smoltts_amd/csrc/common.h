@@ -61,6 +61,7 @@ struct SampleArgs {
   int step;
   int frame_base;
   const int32_t* frames;
+  const int32_t* salt;  // per-row generation counter mixed into the seed (a slot's n-th tenant draws its own numbers), or null
 };
 
 // Launchers implemented across the .hip files (all asynchronous on `stream`).

@@ -50,6 +50,7 @@ struct SmolttsSession {
   // integer state
   int *cur_col, *new_col;    // [B][1+n_fast]
   int *pos, *frames, *done, *mask, *iota, *fastpos;  // [B] each; fastpos [n_fast][B]
+  int* salt;                   // [B] tenants a slot has had: mixed into the sampling seed
   int *stage_slots, *stage_last;                     // [B]
   float* margin;             // [B]
   int* codes;                // [B][max_frames][1+n_fast]
@@ -110,6 +111,7 @@ void carve(SmolttsSession* s, char* base, size_t* total) {
   s->new_col = cv.take<int>(B * H);
   s->pos = cv.take<int>(B);
   s->frames = cv.take<int>(B);
+  s->salt = cv.take<int>(B);
   s->done = cv.take<int>(B);
   s->mask = cv.take<int>(B);
   s->iota = cv.take<int>(B);
@@ -122,19 +124,19 @@ void carve(SmolttsSession* s, char* base, size_t* total) {
 }
 
 __global__ void init_state_kernel(int B, int n_fast, int* iota, int* fastpos, int* pos, int* frames, int* done, int* mask,
-                                  float* margin, int* cur_col, int* new_col) {
+                                  float* margin, int* cur_col, int* new_col, int* salt) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   iota[b] = b;
   for (int i = 0; i < n_fast; ++i) fastpos[i * B + b] = i;
-  pos[b] = 0; frames[b] = 0; done[b] = 1; mask[b] = 0;
+  pos[b] = 0; frames[b] = 0; done[b] = 1; mask[b] = 0; salt[b] = 0;
   margin[b] = INFINITY;
   for (int i = 0; i <= n_fast; ++i) { cur_col[b * (1 + n_fast) + i] = 0; new_col[b * (1 + n_fast) + i] = 0; }
 }
 
 // Restart the listed slots: position = prompt length, counters cleared; only they commit this frame.
 __global__ void slot_reset_kernel(int B, int n_slots, const int* slots, const int* last_row, const int* row_pos, int* pos,
-                                  int* frames, int* done, int* mask, float* margin) {
+                                  int* frames, int* done, int* mask, float* margin, int* salt) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   int hit = -1;
@@ -144,13 +146,14 @@ __global__ void slot_reset_kernel(int B, int n_slots, const int* slots, const in
   if (hit >= 0) {
     pos[b] = row_pos[last_row[hit]] + 1;
     frames[b] = 0; done[b] = 0; margin[b] = INFINITY;
+    salt[b] += 1;  // a new tenant: its samples must not repeat the previous tenant's (same seed, slot and frame numbers)
   }
 }
 
 // Deferred start: the prompt's KV rows are in place; the slot is armed so that the next decode frame takes the last prompt
 // column as its slow-step input at that column's position and emits frame 0 in its own tail (no separate tail launch).
 __global__ void slot_start_kernel(int B, int H, int n_slots, const int* slots, const int* last_row, const int* row_pos,
-                                  const int* grid, int* pos, int* frames, int* done, float* margin, int* cur_col) {
+                                  const int* grid, int* pos, int* frames, int* done, float* margin, int* cur_col, int* salt) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   for (int i = 0; i < n_slots; ++i)
@@ -158,6 +161,7 @@ __global__ void slot_start_kernel(int B, int H, int n_slots, const int* slots, c
       const int lr = last_row[i];
       pos[b] = row_pos[lr];
       frames[b] = 0; done[b] = 0; margin[b] = INFINITY;
+      salt[b] += 1;
       for (int k = 0; k < H; ++k) cur_col[b * H + k] = grid[(long)lr * H + k];
     }
 }
@@ -279,7 +283,7 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
     a.ssq_in_dev = s->ssq; a.eps = c.norm_eps; a.out_dev = s->logits; a.ldo = c.vocab_size;
     ST_TRY(launch_gemm3(a, st));
   }
-  const SampleArgs slow_sa{s->temp, s->min_p, s->seed, 0, 0, s->frames};
+  const SampleArgs slow_sa{s->temp, s->min_p, s->seed, 0, 0, s->frames, s->salt};
   ST_TRY(launch_argmax(s->logits, B, c.vocab_size, c.vocab_size, s->new_col, H, s->margin, s->mask, nullptr, 0, 0, nullptr,
                        nullptr, &slow_sa, st));
   float* xf = s->xt;  // fast input = pre-norm slow hidden (lm/rq_transformer.py:191)
@@ -313,7 +317,7 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
     const bool more = i + 1 < c.n_fast;
     const int off = c.depthwise_wte ? (c.duplicate_code_0 ? i : i + 1) * c.codebook_size : 0;  // generate.py:136-140
     float* xnext = c.has_fast_project_in ? s->xf : s->xt;
-    const SampleArgs fast_sa{s->fast_temp, s->fast_temp > 0.f ? s->min_p : 0.f, s->seed, 1 + i, 0, s->frames};
+    const SampleArgs fast_sa{s->fast_temp, s->fast_temp > 0.f ? s->min_p : 0.f, s->seed, 1 + i, 0, s->frames, s->salt};
     ST_TRY(launch_argmax(s->logits, B, c.codebook_size, c.codebook_size, s->new_col + 1 + i, H, s->margin, s->mask,
                          more ? (const void*)(A + e->w.fast_emb) : nullptr, off, c.fast_dim, more ? xnext : nullptr,
                          more ? &to_fast0 : nullptr, &fast_sa, st));
@@ -520,7 +524,7 @@ int smoltts_session_create(SmolttsEngine* e, void* slab_dev, size_t slab_bytes, 
     }
   }
   hipLaunchKernelGGL(init_state_kernel, dim3((max_batch + 63) / 64), dim3(64), 0, 0, max_batch, e->cfg.n_fast, s->iota,
-                     s->fastpos, s->pos, s->frames, s->done, s->mask, s->margin, s->cur_col, s->new_col);
+                     s->fastpos, s->pos, s->frames, s->done, s->mask, s->margin, s->cur_col, s->new_col, s->salt);
   hipError_t err = hipGetLastError();
   if (err == hipSuccess) err = hipStreamSynchronize(0);
   if (err != hipSuccess) {
@@ -561,7 +565,7 @@ int smoltts_lm_prefill(SmolttsSession* s, const int32_t* grid_dev, const int32_t
   s->stop_on_eos = stop_on_eos;
   ST_TRY(stage_upload(s, slots_host, last_row_host, n_slots, st));
   hipLaunchKernelGGL(slot_reset_kernel, dim3((s->B + 63) / 64), dim3(64), 0, st, s->B, n_slots, s->stage_slots, s->stage_last,
-                     row_pos_dev, s->pos, s->frames, s->done, s->mask, s->margin);
+                     row_pos_dev, s->pos, s->frames, s->done, s->mask, s->margin, s->salt);
   ST_CHECK_HIP(hipGetLastError());
   ST_TRY(embed_rows(s, grid_dev, n_rows, s->xr, st));
   ST_TRY(run_slow_layers(s, s->xr, s->qr, n_rows, row_pos_dev, row_slot_dev, /*publish_hidden=*/false, st));
@@ -624,7 +628,7 @@ int smoltts_lm_prefill_deferred(SmolttsSession* s, const int32_t* grid_dev, cons
   ST_TRY(embed_rows(s, grid_dev, n_rows, s->xr, st));
   ST_TRY(run_slow_layers(s, s->xr, s->qr, n_rows, row_pos_dev, row_slot_dev, /*publish_hidden=*/false, st));
   hipLaunchKernelGGL(slot_start_kernel, dim3((s->B + 63) / 64), dim3(64), 0, st, s->B, 1 + s->e->cfg.n_fast, n_slots, s->stage_slots,
-                     s->stage_last, row_pos_dev, grid_dev, s->pos, s->frames, s->done, s->margin, s->cur_col);
+                     s->stage_last, row_pos_dev, grid_dev, s->pos, s->frames, s->done, s->margin, s->cur_col, s->salt);
   ST_CHECK_HIP(hipGetLastError());
   s->prefilled = true;
   return SMOLTTS_OK;

@@ -120,13 +120,14 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int n_
   Top2 a = top2_merge(top2_merge(sh[0], sh[1]), top2_merge(sh[2], sh[3]));
   if (sa.temp > 0.f) {  // uniform: second pass over the row with perturbed keys
     const int frame = sa.frames ? sa.frames[r] : sa.frame_base + r;
+    const uint64_t seed = sa.seed + (sa.salt ? 0x9E3779B97F4A7C15ULL * (uint64_t)sa.salt[r] : 0ULL);
     const float inv_t = 1.0f / sa.temp;
     const float cut = sa.min_p > 0.f ? logf(sa.min_p) : -INFINITY;
     Top2 k{-INFINITY, 0x7fffffff, -INFINITY};
     for (int j = tid; j < n_cols; j += 256) {
       const float z = (row[j] - a.v1) * inv_t;  // <= 0
       if (z >= cut) {
-        const float u = uniform01(sa.seed, r, frame, sa.step, j);
+        const float u = uniform01(seed, r, frame, sa.step, j);
         const float key = z - logf(-logf(u));
         if (key > k.v1) { k.v1 = key; k.i1 = j; }
       }
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int n_
 int launch_argmax(const float* logits, int n_rows, int n_cols, int64_t ld, int32_t* ids, int ids_stride, float* margin,
                   const int32_t* margin_mask, const void* emb, int emb_row_offset, int dim, float* xnext,
                   const EmitArgs* emit, const SampleArgs* sample, hipStream_t stream) {
-  SampleArgs sa{0.f, 0.f, 0, 0, 0, nullptr};
+  SampleArgs sa{0.f, 0.f, 0, 0, 0, nullptr, nullptr};
   if (sample) sa = *sample;
   EmitDev e{nullptr, nullptr, nullptr, nullptr, nullptr};
   if (emit && emb) e = EmitDev{(char*)emit->x3a, emit->gamma_a, (char*)emit->x3b, emit->gamma_b, emit->ssq};

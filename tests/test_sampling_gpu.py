@@ -87,3 +87,37 @@ def test_session_sampling_modes_and_greedy_limit():
     both = run(temp=1.5, fast_temp=1.5, seed=3)
     assert np.array_equal(both[:, 0, 0], slow_only[:, 0, 0])                  # same key => same first slow draw
     assert not np.array_equal(both[:, :, 1:], slow_only[:, :, 1:])
+
+
+def test_a_slots_next_tenant_draws_its_own_numbers():
+    """Same seed, same slot, same prompt, same frame numbers: the second tenant of a slot must still not repeat the first
+    one's samples (a serving session restarts slots all day), while a fresh session replays the first tenant exactly."""
+    from smoltts_amd.config import TokenConfig
+    from smoltts_amd.engine import LMEngine, LMSession
+    from smoltts_amd.prompt import PromptEncoder
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+    from smoltts_amd.tokenizer import load_tokenizer
+
+    cfg = named_config("tiny")
+    tok = load_tokenizer(None, cfg.codebook_size)
+    tc = TokenConfig.from_tokenizer(tok, cfg)
+    eng = LMEngine(cfg, synthetic_lm_state(cfg, seed=2), tc)
+    prompt = PromptEncoder.from_config(tok, cfg, tc).encode_text_turn("user", "the same request twice")
+
+    def tenant(sess, deferred):
+        sess.prefill([prompt], slots=[0], stop_on_eos=False, defer_frame0=deferred)
+        sess.decode(12)
+        codes, n, _, _ = sess.fetch()
+        return codes[0, : int(n[0])].copy()
+
+    for deferred in (False, True):
+        a = LMSession(eng, 2, max_seq=128, max_rows=64, max_frames=16)
+        a.set_sampling(temp=1.5, fast_temp=1.5, seed=11)
+        first, second = tenant(a, deferred), tenant(a, deferred)
+        a.close()
+        b = LMSession(eng, 2, max_seq=128, max_rows=64, max_frames=16)
+        b.set_sampling(temp=1.5, fast_temp=1.5, seed=11)
+        replay = tenant(b, deferred)
+        b.close()
+        assert np.array_equal(first, replay)
+        assert first.shape == second.shape and not np.array_equal(first, second)
