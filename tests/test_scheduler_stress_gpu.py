@@ -124,3 +124,42 @@ def test_blocking_codec_pool_refills_and_stays_exact():
     for i, (g, w) in enumerate(zip(got, want)):
         assert g is not None and g.shape == w.shape, (i, None if g is None else g.shape, w.shape)
         assert float(np.sqrt(np.mean((g - w) ** 2))) <= 1e-6, i
+
+
+def test_scheduler_with_the_servers_sampling_defaults_runs_clean():
+    """temp 0.5 / fast temp 0 / min_p 0.1 (server/settings.py:33-38): nothing to compare the audio with, but every request must
+    finish with the right amount of finite audio, and the same text asked twice must not come out identical every time."""
+    from smoltts_amd import SmolTTS
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+    from smoltts_amd.config import GenerationSettings
+    from smoltts_amd.server.scheduler import BatchScheduler
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+
+    cfg = named_config("tiny")
+    tts = SmolTTS(state=synthetic_lm_state(cfg, seed=21), config=cfg, mimi_state=synthetic_mimi_state(seed=5))
+    gs = GenerationSettings(default_temp=0.5, default_fast_temp=0.0, min_p=0.1, max_new_tokens=12)
+    sched = BatchScheduler(tts, max_batch=3, frames_per_tick=2, generation_settings=gs)
+    n_req = 30
+    out = [None] * n_req
+
+    def client(i):
+        r = sched.submit("the same words every time", "heart", stream=bool(i % 2), max_new_tokens=4 + i % 9)
+        out[i] = np.concatenate(list(sched.iter_chunks(r)) or [np.zeros(0, np.float32)])
+
+    threads = [threading.Thread(target=client, args=(i,)) for i in range(n_req)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    st = sched.stats()
+    sched.close()
+    assert st["completed"] == n_req and st["failed"] == 0
+    for i, pcm in enumerate(out):
+        n = 4 + i % 9
+        assert pcm is not None and np.isfinite(pcm).all() and pcm.shape[0] % 1920 == 0
+        if i % 2:
+            assert 1920 <= pcm.shape[0] <= (n + 1) * 1920  # streams carry every generated frame (fewer only after <|im_end|>)
+        else:
+            assert pcm.shape[0] <= (n + 1) * 1920
+    same_budget = [out[i] for i in range(1, n_req, 2) if 4 + i % 9 == 9]  # streams with the same text and budget
+    assert len(same_budget) >= 2 and any(a.shape != b.shape or not np.array_equal(a, b) for a in same_budget for b in same_budget if a is not b)
