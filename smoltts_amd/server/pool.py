@@ -101,48 +101,58 @@ def _worker_main(device: str, factory: Callable[[], object], req_q, res_conn) ->
 
 
 class GpuPool:
-    def __init__(self, factory: Callable[[], object], devices: Sequence[int], start_method: str = "spawn", ready_timeout: float = 600.0):
+    def __init__(self, factory: Callable[[], object], devices: Sequence[int], start_method: str = "spawn", ready_timeout: float = 600.0,
+                 respawn: bool = True):
         """``factory``: picklable, called once in every worker to build its scheduler.  ``devices``: GPU indices, one
         worker each (an index may repeat: two replicas on one GPU).  ``start_method``: "spawn" or "forkserver" — never
-        "fork": a forked copy of a process that has used the GPU is not usable."""
+        "fork": a forked copy of a process that has used the GPU is not usable.  ``respawn``: a worker that dies is replaced
+        (same GPU); its requests in flight are failed, later ones are served again by all workers."""
         if start_method not in ("spawn", "forkserver"):
             raise ValueError("start_method must be 'spawn' or 'forkserver'")
         if not devices:
             raise ValueError("no devices")
-        ctx = mp.get_context(start_method)
+        self._ctx = mp.get_context(start_method)
+        self._factory, self._ready_timeout, self._respawn = factory, ready_timeout, respawn
         inherited = os.environ.get("HIP_VISIBLE_DEVICES")
-        self._req_qs = [ctx.Queue() for _ in devices]
-        pipes = [ctx.Pipe(duplex=False) for _ in devices]  # one result pipe per worker: no shared lock, EOF when a worker dies
-        self._res = [r for r, _ in pipes]
-        self._procs = [ctx.Process(target=_worker_main, args=(visible_device(d, inherited), factory, q, w), daemon=True,
-                                   name=f"smoltts-gpu-worker-{i}") for i, (d, q, (_, w)) in enumerate(zip(devices, self._req_qs, pipes))]
-        for p in self._procs:
-            p.start()
-        for _, w in pipes:
-            w.close()  # the workers hold the write ends now
+        self._devices = [visible_device(d, inherited) for d in devices]
+        started = [self._start_worker(i) for i in range(len(devices))]
+        self._procs = [p for p, _, _ in started]
+        self._req_qs = [q for _, q, _ in started]
+        self._res = [r for _, _, r in started]  # one result pipe per worker: no shared lock, EOF when a worker dies
         self._lock = threading.Lock()
         self._reqs: Dict[int, _PoolRequest] = {}
         self._load: List[int] = [0] * len(devices)
         self._dead: List[bool] = [False] * len(devices)  # set (under the lock) by a worker's dispatcher when its pipe ends
+        self._restarts: List[int] = [0] * len(devices)
         self._ids = itertools.count()
         self._closing = False
         for i, conn in enumerate(self._res):  # all workers up (weights loaded, kernels resident) before the first request is taken
-            try:
-                if not conn.poll(ready_timeout):
-                    raise RuntimeError("GPU workers did not come up in time")
-                _, kind, payload = conn.recv()
-            except EOFError:
-                kind, payload = "fatal", f"worker {i} exited during start-up"
-            except RuntimeError:
+            why = self._await_ready(conn, i)
+            if why is not None:
                 self._kill()
-                raise
-            if kind != "ready":
-                self._kill()
-                raise RuntimeError(f"GPU worker failed to start: {payload}")
+                raise RuntimeError(why)
         self._threads = [threading.Thread(target=self._dispatch, args=(i,), name=f"smoltts-pool-dispatch-{i}", daemon=True)
                          for i in range(len(devices))]
         for t in self._threads:
             t.start()
+
+    def _start_worker(self, w: int):
+        q = self._ctx.Queue()
+        r, wr = self._ctx.Pipe(duplex=False)
+        p = self._ctx.Process(target=_worker_main, args=(self._devices[w], self._factory, q, wr), daemon=True, name=f"smoltts-gpu-worker-{w}")
+        p.start()
+        wr.close()  # the worker holds the write end now
+        return p, q, r
+
+    def _await_ready(self, conn, w: int) -> Optional[str]:
+        """None once worker ``w`` has reported ready, else why it did not."""
+        try:
+            if not conn.poll(self._ready_timeout):
+                return "GPU workers did not come up in time"
+            _, kind, payload = conn.recv()
+        except (EOFError, OSError):
+            return f"GPU worker failed to start: worker {w} exited during start-up"
+        return None if kind == "ready" else f"GPU worker failed to start: {payload}"
 
     # ------------------------------------------------------------------ client side (the BatchScheduler interface)
     def submit(self, text: str, voice: str = "heart", stream: bool = False, max_new_tokens: Optional[int] = None) -> _PoolRequest:
@@ -186,7 +196,7 @@ class GpuPool:
         """Front-end view (``GET /v1/stats``): workers alive and requests in flight per worker."""
         with self._lock:
             return {"workers": len(self._procs), "alive": sum(1 for i, p in enumerate(self._procs) if not self._dead[i] and p.is_alive()),
-                    "in_flight": list(self._load)}
+                    "in_flight": list(self._load), "restarts": list(self._restarts)}
 
     def loads(self) -> List[int]:
         """Requests in flight per worker."""
@@ -230,9 +240,14 @@ class GpuPool:
             except (EOFError, OSError):
                 with self._lock:
                     self._dead[w] = True  # from here on submit() avoids this worker; what it holds is failed just below
-                if not self._closing:
-                    self._fail_open(RuntimeError(f"GPU worker {w} died (exit code {self._procs[w].exitcode})"), worker=w)
-                return
+                if self._closing:
+                    return
+                self._procs[w].join(timeout=5)
+                self._fail_open(RuntimeError(f"GPU worker {w} died (exit code {self._procs[w].exitcode})"), worker=w)
+                conn = self._replace(w)
+                if conn is None:
+                    return
+                continue
             with self._lock:
                 req = self._reqs.get(rid)
             if req is None:
@@ -245,6 +260,21 @@ class GpuPool:
             elif kind == "error":
                 name, msg = payload  # a refused request (ValueError) stays one: the HTTP layer answers 400 for it, 500 for the rest
                 self._finish(req, ValueError(msg) if name == "ValueError" else RuntimeError(f"{name}: {msg}"))
+
+    def _replace(self, w: int):
+        """Start a new worker in place of the dead one; its result pipe, or None (not wanted, closing, or it keeps dying)."""
+        if not self._respawn or self._restarts[w] >= 3:
+            return None
+        self._restarts[w] += 1
+        p, q, r = self._start_worker(w)
+        if self._await_ready(r, w) is not None or self._closing:
+            if p.is_alive():
+                p.terminate()
+            return None
+        with self._lock:
+            self._procs[w], self._req_qs[w], self._res[w] = p, q, r
+            self._dead[w] = False
+        return r
 
     def _kill(self) -> None:
         for p in self._procs:

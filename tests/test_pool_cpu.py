@@ -48,7 +48,7 @@ def test_pool_routes_relays_and_balances():
             assert len(set(g[:, 0])) == 1  # one worker served the whole request
             served.append(int(g[0, 0]))
         assert sorted(set(served)) == [0, 1]  # both workers were used, each under its own device mask
-        assert pool.loads() == [0, 0] and pool.stats() == {"workers": 2, "alive": 2, "in_flight": [0, 0]}
+        assert pool.loads() == [0, 0] and pool.stats() == {"workers": 2, "alive": 2, "in_flight": [0, 0], "restarts": [0, 0]}
         assert pool.synthesize("abcd", max_new_tokens=2).shape == (8,)
         # an error raised for one request reaches that client only
         with pytest.raises(ValueError, match="bad request"):  # the type survives the process boundary (HTTP 400, not 500)
@@ -63,7 +63,7 @@ def test_pool_routes_relays_and_balances():
 def test_pool_cancel_and_worker_death():
     from smoltts_amd.server.pool import GpuPool
 
-    pool = GpuPool(functools.partial(make_echo, 0.02), devices=[0, 1], ready_timeout=120)
+    pool = GpuPool(functools.partial(make_echo, 0.02), devices=[0, 1], ready_timeout=120, respawn=False)
     try:
         r = pool.submit("x" * 500, stream=True)  # 10 s of chunks if nobody stops it
         it = pool.iter_chunks(r)
@@ -108,6 +108,30 @@ def test_pool_cancel_and_worker_death():
         assert np.stack(list(pool.iter_chunks(other))).shape == (100, 4)
         g = np.stack(list(pool.iter_chunks(pool.submit("abc"))))
         assert g.shape == (3, 4) and int(g[0, 0]) != int(victim.worker)
+    finally:
+        pool.close()
+
+
+def test_pool_replaces_a_worker_that_died():
+    from smoltts_amd.server.pool import GpuPool
+
+    pool = GpuPool(functools.partial(make_echo, 0.0), devices=[0, 1], ready_timeout=120)
+    try:
+        killer = pool.submit("__die__")
+        with pytest.raises(RuntimeError, match="died"):
+            list(pool.iter_chunks(killer))
+        deadline = time.time() + 60
+        while pool.stats()["alive"] < 2 and time.time() < deadline:
+            time.sleep(0.1)
+        st = pool.stats()
+        assert st["alive"] == 2 and st["restarts"][killer.worker] == 1
+        served = set()
+        for i in range(8):  # both workers serve again, the replacement under the dead one's device mask
+            hold = pool.submit("h" * 30)  # goes to the first idle worker, the next request to the other one
+            g = np.stack(list(pool.iter_chunks(pool.submit("abc"))))
+            h = np.stack(list(pool.iter_chunks(hold)))
+            served |= {int(g[0, 0]), int(h[0, 0])}
+        assert served == {0, 1}
     finally:
         pool.close()
 
