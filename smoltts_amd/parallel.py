@@ -78,4 +78,7 @@ def all_reduce_sum(value: float, device) -> float:
 
 def barrier() -> None:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":  # RCCL: name the rank's own GPU instead of letting the collective guess it
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
