@@ -129,7 +129,18 @@ def create_app(model=None, settings: Optional[dict] = None, scheduler=None) -> F
     """``model``: a ``smoltts_amd.SmolTTS`` (or any object with ``__call__``/``stream``); ``scheduler``: an
     optional ``BatchScheduler`` so that concurrent requests are decoded together (handlers are plain
     ``def`` and run in FastAPI's thread pool; the reference's ``async def`` handlers serialise requests)."""
-    app = FastAPI()
+    from contextlib import asynccontextmanager
+
+    @asynccontextmanager
+    async def lifespan(_app):
+        yield
+        if scheduler is not None and hasattr(scheduler, "close"):  # finish what is in flight, then release the GPU(s)
+            try:
+                scheduler.close(drain=True)
+            except TypeError:  # a pool: its workers drain their own schedulers
+                scheduler.close()
+
+    app = FastAPI(lifespan=lifespan)
     app.include_router(openai_router)
     app.include_router(eleven_router)
     app.state.settings = settings

@@ -97,7 +97,10 @@ def _worker_main(device: str, factory: Callable[[], object], req_q, res_conn) ->
                 if req is not None:
                     sched.cancel(req)
     finally:
-        sched.close()
+        try:
+            sched.close(drain=True)  # a BatchScheduler finishes what it has accepted
+        except TypeError:
+            sched.close()
 
 
 class GpuPool:

@@ -89,6 +89,7 @@ class BatchScheduler:
         self._tick_no = 0                       # ticks queued so far
         self._counts = {"completed": 0, "cancelled": 0, "failed": 0, "frames_delivered": 0}
         self._dead: Optional[Exception] = None  # why the worker stopped
+        self._draining = False
         self._held: Optional[_Request] = None   # next in line, waiting for room in a prefill call
         self._gpu_wait_s = 0.0                  # time the worker spent waiting for the GPU (small => the host is the limit)
         self._t0 = time.time()
@@ -99,6 +100,8 @@ class BatchScheduler:
     def submit(self, text: str, voice: str = "heart", stream: bool = False, max_new_tokens: Optional[int] = None) -> _Request:
         if self._dead is not None:  # the worker is gone (engine failure or close): nobody would ever answer
             raise RuntimeError(f"scheduler is not running: {self._dead}")
+        if self._draining:
+            raise RuntimeError("scheduler is not running: shutting down")
         req = _Request(text, voice, stream, min(max_new_tokens or self.settings.max_new_tokens, self.settings.max_new_tokens))
         self._pending.put(req)
         if self._dead is not None:  # lost the race with a failing worker: answer it ourselves
@@ -131,7 +134,15 @@ class BatchScheduler:
         step costs the same with or without it.  Nothing more is delivered except the end marker."""
         req.cancelled = True
 
-    def close(self) -> None:
+    def close(self, drain: bool = False, timeout: float = 300.0) -> None:
+        """Stop the worker.  ``drain``: take no new requests but finish the ones in the books first (a server shutting down);
+        otherwise requests in flight are answered with an error."""
+        if drain and self._dead is None:
+            self._draining = True
+            deadline = time.time() + timeout
+            while (self._thread.is_alive() and time.time() < deadline and
+                   (self._active or self._held is not None or not self._pending.empty() or self._codec_backlog() or self._deliveries)):
+                time.sleep(0.01)
         self._stop.set()
         self._thread.join(timeout=30)
         for name in ("_batch_codec", "_stream_codec"):

@@ -178,3 +178,27 @@ def test_scheduler_splits_admissions_that_exceed_the_prefill_workspace_and_fails
     with pytest.raises(RuntimeError, match="not running"):
         sched.submit("anyone there?")
     sched.close()
+
+
+def test_scheduler_close_with_drain_finishes_what_it_accepted():
+    from smoltts_amd import SmolTTS
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+    from smoltts_amd.config import GenerationSettings
+    from smoltts_amd.server.scheduler import BatchScheduler
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+
+    cfg = named_config("tiny")
+    tts = SmolTTS(state=synthetic_lm_state(cfg, seed=21), config=cfg, mimi_state=synthetic_mimi_state(seed=5))
+    gs = GenerationSettings.greedy(max_new_tokens=20)
+    want = tts("finish me first", "sky", generation_settings=gs)
+    sched = BatchScheduler(tts, max_batch=2, frames_per_tick=2, generation_settings=gs)
+    reqs = [sched.submit("finish me first", "sky", stream=bool(i % 2)) for i in range(5)]  # more than the slots: some still queued
+    sched.close(drain=True)
+    with pytest.raises(RuntimeError, match="not running"):
+        sched.submit("too late")
+    for i, r in enumerate(reqs):
+        got = np.concatenate(list(sched.iter_chunks(r)))
+        if not i % 2:
+            assert got.shape == want.shape and float(np.sqrt(np.mean((got - want) ** 2))) <= 1e-6
+        else:
+            assert got.shape[0] == 21 * 1920
