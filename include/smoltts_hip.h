@@ -103,6 +103,13 @@ typedef struct SmolttsLMWeights {
   SmolttsBlockWeights fast_layers[SMOLTTS_MAX_FAST_LAYERS];
 } SmolttsLMWeights;
 
+enum {  /* storage of the slow transformer's KV cache */
+  SMOLTTS_KV_F32 = 0,   /* fp32 (default): K/V exactly as computed */
+  SMOLTTS_KV_BF16 = 1   /* bf16: K (after RoPE) and V rounded to nearest even once, when written; half the attention stream.
+                           Changes the arithmetic (the oracle mirrors it with kv_bf16=True); the reference keeps K/V in its
+                           activation dtype (lm/cache.py:6-22), i.e. bf16 for a bf16 checkpoint */
+};
+
 typedef struct SmolttsEngine SmolttsEngine;
 typedef struct SmolttsSession SmolttsSession;
 
@@ -119,6 +126,12 @@ size_t smoltts_session_slab_bytes(const SmolttsEngine* e, int32_t max_batch, int
 int smoltts_session_create(SmolttsEngine* e, void* slab_dev, size_t slab_bytes, int32_t max_batch,
                            int32_t max_seq, int32_t max_rows, int32_t max_frames,
                            SmolttsSession** out);
+/* The same with a choice of KV-cache storage (SMOLTTS_KV_*); the plain forms above are kv_format = SMOLTTS_KV_F32. */
+size_t smoltts_session_slab_bytes_kv(const SmolttsEngine* e, int32_t max_batch, int32_t max_seq,
+                                     int32_t max_rows, int32_t max_frames, int32_t kv_format);
+int smoltts_session_create_kv(SmolttsEngine* e, void* slab_dev, size_t slab_bytes, int32_t max_batch,
+                              int32_t max_seq, int32_t max_rows, int32_t max_frames, int32_t kv_format,
+                              SmolttsSession** out);
 void smoltts_session_destroy(SmolttsSession* s);
 
 /* Prefill: run the slow transformer over n_rows prompt tokens (packed over utterances) and emit
@@ -155,7 +168,8 @@ int smoltts_lm_prefill_deferred(SmolttsSession* s, const int32_t* grid_dev, cons
 /* Decode n_frames further frames for every slot of the session: each frame feeds the previous
  * column back (slow step at the slot's next position), then slow head + n_fast depth steps, all
  * greedy and on device; the frame loop is a captured hipGraph replayed n_frames times.  Slots that
- * are done (emitted <|im_end|> with stop_on_eos, or reached max_frames) are frozen. */
+ * are done (emitted <|im_end|> with stop_on_eos, reached max_frames, or filled their context: the next
+ * token would land at position max_seq) are frozen. */
 int smoltts_lm_decode(SmolttsSession* s, int32_t n_frames, void* stream);
 
 /* Sampling mode (reference GenerationSettings, lm/generate.py:12-16): temp / fast_temp <= 0 select
@@ -171,6 +185,8 @@ int smoltts_session_set_sampling(SmolttsSession* s, float temp, float fast_temp,
  *   margin     float [max_batch]   smallest top-1/top-2 logit gap seen by the slot's argmaxes */
 int smoltts_session_outputs(SmolttsSession* s, int32_t** codes_dev, int32_t** n_frames_dev,
                             int32_t** done_dev, float** margin_dev);
+/* int32 [max_batch]: where each slot's smallest gap occurred, frame * 64 + step (step 0 = slow id, i = depth code i-1). */
+int smoltts_session_margin_at(SmolttsSession* s, int32_t** margin_at_dev);
 
 /* ------------------------------------------------------------------------------ Mimi decoder */
 #define SMOLTTS_MIMI_MAX_LAYERS 16
@@ -368,6 +384,7 @@ typedef struct SmolttsGemm3Args {
                                   V row (softmax over one key): V is also written as the X3 operand [M][n_q_heads*64] of
                                   the output projection (each kv head repeated for its query heads) and no attention
                                   launch is needed */
+  int32_t kv_format;           /* EPI_QKV_ROPE: SMOLTTS_KV_F32 | SMOLTTS_KV_BF16 storage of k_cache_dev / v_cache_dev */
 } SmolttsGemm3Args;
 
 int smoltts_k_gemm3(const SmolttsGemm3Args* a, void* stream);
@@ -376,17 +393,14 @@ int smoltts_k_x3_pack(const float* x_dev, int64_t ldx, int32_t n_rows, int32_t d
                       const float* gamma_a_dev, void* x3b_dev, const float* gamma_b_dev, float* ssq_dev,
                       void* stream);
 
-/* Measurement hook (bench.py): between begin and end, every GEMM launch whose prologue/epilogue
- * (and N, when n_filter > 0) match is bracketed by a pair of hipEvents on the stream it is launched
- * on.  Use with eager launches only (SMOLTTS_NO_GRAPH=1); events cannot be recorded into a graph
- * being captured.  profile_end synchronises the events and returns the summed kernel time. */
-int smoltts_profile_begin(int32_t prologue, int32_t epilogue, int32_t n_filter, int32_t max_launches);
-int smoltts_profile_end(float* total_ms, int32_t* n_launches);
-/* Measurement aid for graph replays: while set (epilogue >= 0), every bf16 GEMM launch with that
- * epilogue (and N == n_filter when n_filter > 0; EPI_RESID excluded: not idempotent) is issued twice.
- * Capture a frame graph with and without it: the time difference per extra launch is the kernel's
- * in-situ duration.  smoltts_session_drop_graph makes the next smoltts_lm_decode re-capture. */
-int smoltts_debug_duplicate(int32_t epilogue, int32_t n_filter);
+/* Measurement aid of ONE session (bench.py, tools/marginal_cost.py): while code >= 0, every launch of that kernel class
+ * inside this session's frames is issued twice -- code = the GEMM's epilogue (and N == n_filter when n_filter > 0;
+ * EPI_RESID is refused: not idempotent), 100 = depth (<= 16 keys) attention, 101 = slow attention.  The session's
+ * captured graphs are dropped; time a frame graph with and without it: the difference per extra launch is the kernel's
+ * in-situ duration.  Other sessions are unaffected (there is no process-global debug state in this library; the event /
+ * cycle-stamp hooks of tools/ exist only in diagnostic builds with -DSMOLTTS_DEBUG_HOOKS, built to a separate path). */
+int smoltts_session_measure_duplicate(SmolttsSession* s, int32_t code, int32_t n_filter);
+/* Forget the captured frame graphs (the next smoltts_lm_decode captures again). */
 int smoltts_session_drop_graph(SmolttsSession* s);
 
 /* GQA attention of one query row per (row, kv head) over the slot's cache prefix:
@@ -396,6 +410,12 @@ int smoltts_k_attention(const float* q_dev, const float* k_cache_dev, const floa
                         const int32_t* row_pos_dev, const int32_t* row_slot_dev, int32_t n_rows,
                         int32_t n_q_heads, int32_t n_kv_heads, int32_t cache_len, int32_t window,
                         float* out_dev, void* out_x3_dev, void* stream);
+
+/* The same over a cache stored in kv_format (SMOLTTS_KV_BF16: caches of more than 16 entries). */
+int smoltts_k_attention_kv(const float* q_dev, const void* k_cache_dev, const void* v_cache_dev,
+                           const int32_t* row_pos_dev, const int32_t* row_slot_dev, int32_t n_rows,
+                           int32_t n_q_heads, int32_t n_kv_heads, int32_t cache_len, int32_t window,
+                           float* out_dev, void* out_x3_dev, int32_t kv_format, void* stream);
 
 /* x[r] = E_text[cols[r][0]] + keep * sum_k E_cb[cols[r][1+k] + k*codebook_size] */
 int smoltts_k_embed(const int32_t* cols_dev, int32_t n_rows, int32_t n_code_rows,

@@ -159,6 +159,7 @@ class _Block:
         self.attn_norm = g("attention_norm.weight")
         self.ffn_norm = g("ffn_norm.weight")
         self.n_head, self.n_kv, self.hd, self.eps = n_head, n_kv, hd, eps
+        self.kv_bf16 = False  # engine option kv_dtype="bf16": K (after RoPE) and V are rounded to bf16 once, as they enter the cache
 
     def qkv(self, x: Tensor, cs: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
         """x (..., d) -> q (..., H, hd), k, v (..., KV, hd) with RoPE applied (modeling :542-552)."""
@@ -168,7 +169,10 @@ class _Block:
         q = q.reshape(*q.shape[:-1], self.n_head, self.hd)
         k = k.reshape(*k.shape[:-1], self.n_kv, self.hd)
         v = v.reshape(*v.shape[:-1], self.n_kv, self.hd)
-        return apply_rope(q, cs), apply_rope(k, cs), v
+        q, k = apply_rope(q, cs), apply_rope(k, cs)
+        if self.kv_bf16:  # round to nearest even, what the engine's cache write does; every use of K / V sees the rounded values
+            k, v = k.bfloat16().float(), v.bfloat16().float()
+        return q, k, v
 
     def mlp(self, h: Tensor) -> Tensor:
         hn = rms_norm(h, self.ffn_norm, self.eps)
@@ -211,7 +215,10 @@ class LMOracle:
         state: Dict[str, Tensor],
         embed_mask: str = "torch",
         rope_bf16: bool = True,
+        kv_bf16: bool = False,
     ):
+        """``kv_bf16``: mirror of the engine's bf16 KV-cache option (slow transformer only; the depth transformer's 8-entry
+        per-frame cache stays fp32 there too).  The reference itself keeps K/V in the activation dtype (lm/cache.py:6-22)."""
         assert embed_mask in ("torch", "mlx")
         self.cfg, self.embed_mask = cfg, embed_mask
         st = {k.replace("_orig_mod.", ""): v for k, v in state.items()}
@@ -230,6 +237,8 @@ class LMOracle:
             _Block(st, f"fast_layers.{i}.", cfg.fast_n_head, cfg.fast_n_local_heads, cfg.fast_head_dim, cfg.norm_eps)
             for i in range(cfg.n_fast_layer)
         ]
+        for L in self.layers:
+            L.kv_bf16 = kv_bf16
         if "fast_project_in.weight" in st:  # modeling :339-342 (Linear *with* bias)
             self.proj_w, self.proj_b = f("fast_project_in.weight"), f("fast_project_in.bias")
         else:

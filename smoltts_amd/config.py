@@ -172,6 +172,20 @@ class GenerationSettings:
     min_p: Optional[float] = None
     max_new_tokens: int = 1024
     seed: Optional[int] = None  # extension: None draws a fresh seed per generator
+    # What ``min_p`` does.  "reference": exactly what lm/utils/samplers.py:22-28 computes -- the threshold is built from the
+    # token's OWN log-probability (``top_logprobs`` is the same array as ``sorted_logprobs``), so nothing is ever removed
+    # and the draw is plain categorical over logits / temp.  "intended": the rule the code was taken from (MLX examples):
+    # keep tokens with p >= min_p * p_max.  The drop-in default is what the reference does.
+    min_p_mode: str = "reference"
+
+    def __post_init__(self):
+        if self.min_p_mode not in ("reference", "intended"):
+            raise ValueError(f"min_p_mode must be 'reference' or 'intended', got {self.min_p_mode!r}")
+
+    @property
+    def effective_min_p(self) -> float:
+        """The cut the device sampler applies (0 = none)."""
+        return float(self.min_p or 0.0) if self.min_p_mode == "intended" else 0.0
 
     @classmethod
     def greedy(cls, max_new_tokens: int = 1024) -> "GenerationSettings":

@@ -33,6 +33,13 @@ int smoltts_k_attention(const float* q_dev, const float* k_cache_dev, const floa
                           window, out_dev, out_x3_dev, (hipStream_t)stream);
 }
 
+int smoltts_k_attention_kv(const float* q_dev, const void* k_cache_dev, const void* v_cache_dev, const int32_t* row_pos_dev,
+                           const int32_t* row_slot_dev, int32_t n_rows, int32_t n_q_heads, int32_t n_kv_heads,
+                           int32_t cache_len, int32_t window, float* out_dev, void* out_x3_dev, int32_t kv_format, void* stream) {
+  return launch_attention(q_dev, k_cache_dev, v_cache_dev, row_pos_dev, row_slot_dev, n_rows, n_q_heads, n_kv_heads, cache_len,
+                          window, out_dev, out_x3_dev, (hipStream_t)stream, kv_format);
+}
+
 int smoltts_k_embed(const int32_t* cols_dev, int32_t n_rows, int32_t n_code_rows, const void* text_emb_dev,
                     const void* cb_emb_dev, int32_t dim, int32_t codebook_size, int32_t cb_first_offset, int32_t mask_mode,
                     int32_t sem_start, int32_t sem_end, float* x_dev, void* stream) {
@@ -49,7 +56,7 @@ int smoltts_k_argmax(const float* logits_dev, int32_t n_rows, int32_t n_cols, in
 
 int smoltts_k_sample(const float* logits_dev, int32_t n_rows, int32_t n_cols, int64_t ld, float temp, float min_p, uint64_t seed,
                      int32_t frame_base, int32_t step, int32_t* ids_dev, void* stream) {
-  const SampleArgs sa{temp, min_p, seed, step, frame_base, nullptr, nullptr};
+  const SampleArgs sa{temp, min_p, seed, step, frame_base, nullptr, nullptr, nullptr};
   return launch_argmax(logits_dev, n_rows, n_cols, ld, ids_dev, 1, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, &sa,
                        (hipStream_t)stream);
 }

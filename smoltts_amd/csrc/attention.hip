@@ -20,14 +20,24 @@ namespace smoltts {
 
 struct AttnDev {
   const float* q;
-  const float* kc;
-  const float* vc;
+  const void* kc;   // fp32 or bf16 (template parameter KB of the long-cache kernels)
+  const void* vc;
   const int* row_pos;
   const int* row_slot;
   float* out;
   char* out_x3;
   int n_q_heads, n_kv_heads, cache_len, window, score_cap;
 };
+
+// 4 consecutive cache elements starting at element index e: fp32 (16 B) or bf16 (8 B, widened exactly)
+template <bool KB>
+__device__ __forceinline__ float4 load_kv4(const void* base, long e) {
+  if (KB) {
+    const uint2 v = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(base) + e);
+    return make_float4(bf16_lo(v.x), bf16_hi(v.x), bf16_lo(v.y), bf16_hi(v.y));
+  }
+  return *reinterpret_cast<const float4*>(static_cast<const float*>(base) + e);
+}
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -56,7 +66,7 @@ constexpr int ATT_UN = 8;  // keys per lane group and pass: 8 K + 8 V rows in fl
 // owning every (4*nwaves)-th key), K and V rows of a pass all in flight together, one rescale per
 // 8-key block (9 exps per 8 keys and head); the groups' (max, sum, acc) triples are merged in fixed
 // order: the 4 groups of a wave with shuffles, the waves through LDS.  Two barriers in total.
-template <int G>
+template <int G, bool KB>
 __global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int nwaves = blockDim.x >> 6;
@@ -78,8 +88,7 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
   const int j_lo = (p.window > 0 && pos + 1 > p.window) ? pos + 1 - p.window : 0;
   const int L = pos + 1 - j_lo;
   const long cbase = (((long)slot * p.n_kv_heads + h) * p.cache_len + j_lo) * 64;
-  const float* K = p.kc + cbase + dl * 4;
-  const float* V = p.vc + cbase + dl * 4;
+  const long ebase = cbase + dl * 4;
   const int step = 4 * nwaves;
 
   float4 qv[G];
@@ -99,8 +108,8 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
     for (int u = 0; u < ATT_UN; ++u) {
       const int j = j0 + u * step;
       const bool ok = j < L;
-      kv[u] = ok ? *reinterpret_cast<const float4*>(K + (long)j * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
-      vv[u] = ok ? *reinterpret_cast<const float4*>(V + (long)j * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+      kv[u] = ok ? load_kv4<KB>(p.kc, ebase + (long)j * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
+      vv[u] = ok ? load_kv4<KB>(p.vc, ebase + (long)j * 64) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
 //       D_t[i] = O[dim 16q + 4i + t][row r]  ->  the lane owns out[row r][16q .. 16q + 16)
 // so no value ever crosses lanes except the row maximum (two shuffles per tile and head).  Rows of a tile may belong to
 // different slots (utterance boundaries in the packed prompt): one pass per distinct slot, the other rows masked.
-template <int G>
+template <int G, bool KB>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnDev p, int n_rows) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = lane & 15, q = lane >> 4;
@@ -234,14 +243,14 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnDev p, int n_rows
     float4 kn[4], vn[4];
     auto fetch_tile = [&](int j0) {
       const int jk = j0 + r;
-      const float* kp = p.kc + cbase + (long)jk * 64 + q * 16;
+      const long ke = cbase + (long)jk * 64 + q * 16;
       const bool okk = jk <= hi;
 #pragma unroll
-      for (int c4 = 0; c4 < 4; ++c4) kn[c4] = okk ? *reinterpret_cast<const float4*>(kp + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int c4 = 0; c4 < 4; ++c4) kn[c4] = okk ? load_kv4<KB>(p.kc, ke + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int jv = j0 + 4 * q + c;
-        vn[c] = jv <= hi ? *reinterpret_cast<const float4*>(p.vc + cbase + (long)jv * 64 + r * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        vn[c] = jv <= hi ? load_kv4<KB>(p.vc, cbase + (long)jv * 64 + r * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     };
     fetch_tile((lo & ~15) + 16 * wave);
@@ -357,8 +366,8 @@ __global__ __launch_bounds__(256) void attn_short_kernel(AttnDev p, int n_pairs)
   for (int u = 0; u < UN; ++u) {
     const int j = u * 4 + kk;
     const bool v = j < L;
-    kv[u] = v ? *reinterpret_cast<const float4*>(p.kc + cbase + (long)j * 64 + dl * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    vv[u] = v ? *reinterpret_cast<const float4*>(p.vc + cbase + (long)j * 64 + dl * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    kv[u] = v ? load_kv4<false>(p.kc, cbase + (long)j * 64 + dl * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    vv[u] = v ? load_kv4<false>(p.vc, cbase + (long)j * 64 + dl * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
   for (int g = 0; g < G; ++g) {
@@ -403,25 +412,12 @@ __global__ __launch_bounds__(256) void attn_short_kernel(AttnDev p, int n_pairs)
   }
 }
 
-int debug_dup_code();  // gemm3.hip (smoltts_debug_duplicate): 100 = duplicate short-cache attention, 101 = long-cache
-
-static int launch_attention_once(const float* q, const float* kc, const float* vc, const int32_t* row_pos, const int32_t* row_slot,
-                                 int n_rows, int n_q_heads, int n_kv_heads, int cache_len, int window, float* out, void* out_x3,
-                                 hipStream_t stream);
-
-int launch_attention(const float* q, const float* kc, const float* vc, const int32_t* row_pos, const int32_t* row_slot,
+int launch_attention(const float* q, const void* kc, const void* vc, const int32_t* row_pos, const int32_t* row_slot,
                      int n_rows, int n_q_heads, int n_kv_heads, int cache_len, int window, float* out, void* out_x3,
-                     hipStream_t stream) {
-  const int dup = debug_dup_code();  // measurement aid (tools/marginal_cost.py): the launch is idempotent
-  const int reps = (dup == 100 && cache_len <= 16) || (dup == 101 && cache_len > 16) ? 2 : 1;
-  for (int i = 0; i < reps; ++i)
-    ST_TRY(launch_attention_once(q, kc, vc, row_pos, row_slot, n_rows, n_q_heads, n_kv_heads, cache_len, window, out, out_x3, stream));
-  return SMOLTTS_OK;
-}
-
-static int launch_attention_once(const float* q, const float* kc, const float* vc, const int32_t* row_pos, const int32_t* row_slot,
-                                 int n_rows, int n_q_heads, int n_kv_heads, int cache_len, int window, float* out, void* out_x3,
-                                 hipStream_t stream) {
+                     hipStream_t stream, int kv_format) {
+  ST_REQUIRE(kv_format == SMOLTTS_KV_F32 || (kv_format == SMOLTTS_KV_BF16 && cache_len > 16), SMOLTTS_E_INVALID,
+             "attention: kv_format %d unsupported here (bf16 caches need more than 16 entries)", kv_format);
+  const bool kb = kv_format == SMOLTTS_KV_BF16;
   ST_REQUIRE(q && kc && vc && row_pos && row_slot && (out || out_x3), SMOLTTS_E_INVALID, "attention: null pointer");
   ST_REQUIRE(n_rows > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0 && cache_len > 0, SMOLTTS_E_INVALID,
              "attention: bad shape rows=%d q_heads=%d kv_heads=%d cache_len=%d", n_rows, n_q_heads, n_kv_heads, cache_len);
@@ -460,17 +456,22 @@ static int launch_attention_once(const float* q, const float* kc, const float* v
   if ((long)n_rows * n_kv_heads >= 1024 && getenv("SMOLTTS_NO_MFMA_ATTN") == nullptr) {  // prompt prefill, codec transformer
     // one query head per wave: the longest row tile (the critical path of the launch) is G times shorter, and the K / V
     // tiles re-read by the G waves of a kv group come from L2
-    hipLaunchKernelGGL(attn_prefill_kernel<1>, dim3((n_rows + 15) / 16, n_q_heads), dim3(256), 0, stream, d, n_rows);
+    if (kb) hipLaunchKernelGGL((attn_prefill_kernel<1, true>), dim3((n_rows + 15) / 16, n_q_heads), dim3(256), 0, stream, d, n_rows);
+    else hipLaunchKernelGGL((attn_prefill_kernel<1, false>), dim3((n_rows + 15) / 16, n_q_heads), dim3(256), 0, stream, d, n_rows);
     ST_CHECK_HIP(hipGetLastError());
     return SMOLTTS_OK;
   }
   const dim3 grid(n_rows, n_kv_heads);
 #define ST_ATTN(GG)                                                                          \
   case GG:                                                                                    \
-    if (lds > 64 * 1024)                                                                      \
-      ST_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<GG>,                          \
+    if (lds > 64 * 1024) {                                                                    \
+      ST_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<GG, false>,                   \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(attn_kernel<GG>, grid, dim3(nwaves * 64), lds, stream, d);             \
+      ST_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<GG, true>,                    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    }                                                                                         \
+    if (kb) hipLaunchKernelGGL((attn_kernel<GG, true>), grid, dim3(nwaves * 64), lds, stream, d); \
+    else hipLaunchKernelGGL((attn_kernel<GG, false>), grid, dim3(nwaves * 64), lds, stream, d);    \
     break;
   switch (G) {
     ST_ATTN(1)

@@ -62,6 +62,7 @@ struct SampleArgs {
   int frame_base;
   const int32_t* frames;
   const int32_t* salt;  // per-row generation counter mixed into the seed (a slot's n-th tenant draws its own numbers), or null
+  int32_t* margin_at;   // greedy only, optional: [rows] receives frame * 64 + step where the row's smallest top-2 gap occurred
 };
 
 // Launchers implemented across the .hip files (all asynchronous on `stream`).
@@ -69,9 +70,11 @@ int launch_gemm(const SmolttsGemmArgs& a, hipStream_t stream);
 int launch_gemm3(const SmolttsGemm3Args& a, hipStream_t stream);
 int launch_x3_pack(const float* x, int64_t ldx, int n_rows, int dim, void* x3a, const float* gamma_a, void* x3b,
                    const float* gamma_b, float* ssq, hipStream_t stream);
-int launch_attention(const float* q, const float* kc, const float* vc, const int32_t* row_pos,
+// kc / vc: [slot][kv head][cache_len][64] in fp32 (kv_format SMOLTTS_KV_F32) or bf16 (SMOLTTS_KV_BF16; caches of more than 16 entries only)
+int launch_attention(const float* q, const void* kc, const void* vc, const int32_t* row_pos,
                      const int32_t* row_slot, int n_rows, int n_q_heads, int n_kv_heads,
-                     int cache_len, int window, float* out, void* out_x3, hipStream_t stream);
+                     int cache_len, int window, float* out, void* out_x3, hipStream_t stream,
+                     int kv_format = SMOLTTS_KV_F32);
 int launch_embed(const int32_t* cols, int n_rows, int n_code_rows, const void* text_emb,
                  const void* cb_emb, int dim, int codebook_size, int cb_first_offset, int mask_mode,
                  int sem_start, int sem_end, int text_rows, int cb_rows, float* x, const EmitArgs* emit,

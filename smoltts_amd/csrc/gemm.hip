@@ -50,6 +50,7 @@ struct GemmDev {
 };
 
 // cycle stamps of workgroup (0,0): [wave][slot] = {s_memtime, s_memrealtime}
+#ifdef SMOLTTS_DEBUG_HOOKS
 #define STAMP(k)                                                                              \
   do {                                                                                        \
     if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {                        \
@@ -57,6 +58,9 @@ struct GemmDev {
       p.stamps[(wave * 8 + (k)) * 2 + 1] = wall_clock64();                                    \
     }                                                                                         \
   } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ long row_off(int m, int rpb, long ld, long bstride) {
   if (rpb <= 0) return (long)m * ld;
@@ -471,7 +475,11 @@ static int launch_mt(const GemmDev& d, int nwaves, hipStream_t stream) {
   return launch_one<WF32, 4, 2, PRO, EPI>(d, nwaves, stream);
 }
 
-// ---- measurement hook (smoltts_profile_begin/end): hipEvent pairs around matching launches
+static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream);
+
+#ifdef SMOLTTS_DEBUG_HOOKS
+// ---- diagnostic builds only (python -m smoltts_amd.build --variant hooks; never in the product library):
+// hipEvent pairs around matching launches (smoltts_profile_begin/end) and the in-kernel cycle stamp buffer
 namespace {
 struct ProfileState {
   bool on = false;
@@ -480,7 +488,6 @@ struct ProfileState {
 } g_prof;
 }  // namespace
 
-static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream);
 static unsigned long long* g_stamps = nullptr;
 
 unsigned long long* debug_stamp_buffer() { return g_stamps; }
@@ -504,6 +511,9 @@ int launch_gemm(const SmolttsGemmArgs& a, hipStream_t stream) {
   profile_hook_end(i, stream);
   return rc;
 }
+#else
+int launch_gemm(const SmolttsGemmArgs& a, hipStream_t stream) { return launch_gemm_impl(a, stream); }
+#endif
 
 static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
   ST_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, SMOLTTS_E_INVALID, "gemm: empty shape M=%d N=%d K=%d", a.M, a.N, a.K);
@@ -527,7 +537,9 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
   d.rope = a.rope_dev; d.row_pos = a.row_pos_dev; d.row_slot = a.row_slot_dev;
   d.kc = a.k_cache_dev; d.vc = a.v_cache_dev; d.n_q_heads = a.n_q_heads; d.n_kv_heads = a.n_kv_heads;
   d.cache_len = a.cache_len;
+#ifdef SMOLTTS_DEBUG_HOOKS
   d.stamps = g_stamps;
+#endif
   const int nchunks = a.K / 32;
   // waves split K: keep ~3 chunks per wave, at most 16 waves
   int nwaves = (nchunks + 2) / 3;
@@ -591,6 +603,7 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
 
 }  // namespace smoltts
 
+#ifdef SMOLTTS_DEBUG_HOOKS
 extern "C" {
 
 // undocumented diagnostic: device buffer of 16 waves x 8 slots x 2 u64 receiving cycle stamps
@@ -635,3 +648,4 @@ int smoltts_profile_end(float* total_ms, int32_t* n_launches) {
 }
 
 }  // extern "C"
+#endif  // SMOLTTS_DEBUG_HOOKS

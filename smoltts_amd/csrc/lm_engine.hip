@@ -18,7 +18,7 @@
 
 #include <new>
 
-#include "common.h"
+#include "embed_dev.h"
 
 using namespace smoltts;
 
@@ -45,7 +45,8 @@ struct SmolttsSession {
   float* ssq;                // [rows][dim/16] partial sums of squares of the stream
   float* logits;             // [B][max(vocab, codebook)]
   // caches
-  float *kc, *vc;            // [n_layer][B][KV][max_seq][64]
+  char *kc, *vc;             // [n_layer][B][KV][max_seq][64] in fp32 or bf16 (kv_format)
+  int kv_format;
   float *fkc, *fvc;          // [n_fast_layer][B][FKV][n_fast][64]
   // integer state
   int *cur_col, *new_col;    // [B][1+n_fast]
@@ -53,6 +54,7 @@ struct SmolttsSession {
   int* salt;                   // [B] tenants a slot has had: mixed into the sampling seed
   int *stage_slots, *stage_last;                     // [B]
   float* margin;             // [B]
+  int* margin_at;            // [B] frame * 64 + step of the slot's smallest top-2 gap
   int* codes;                // [B][max_frames][1+n_fast]
   // host staging (pinned)
   int* h_stage;                // STAGE_RING pinned areas of 2*B ints, used in turn
@@ -64,6 +66,8 @@ struct SmolttsSession {
   hipGraphExec_t tail_exec;    // the tail alone (slow head + depth steps + commit) as run after a prefill
   bool tail_ready;
   bool prefilled;
+  // measurement aid of THIS session (smoltts_session_measure_duplicate): launches of one kernel class are issued twice
+  int dup_code, dup_n;
 };
 
 namespace {
@@ -101,9 +105,9 @@ void carve(SmolttsSession* s, char* base, size_t* total) {
   s->x3h = cv.take<char>(R16 * imx * 6);
   s->ssq = cv.take<float>(R16 * (dmax / 16));
   s->logits = cv.take<float>(B * (size_t)imax(c.vocab_size, c.codebook_size));
-  const size_t kv = (size_t)c.n_layer * B * c.n_kv_head * s->max_seq * 64;
-  s->kc = cv.take<float>(kv);
-  s->vc = cv.take<float>(kv);
+  const size_t kv = (size_t)c.n_layer * B * c.n_kv_head * s->max_seq * 64 * (s->kv_format == SMOLTTS_KV_BF16 ? 2 : 4);
+  s->kc = cv.take<char>(kv);
+  s->vc = cv.take<char>(kv);
   const size_t fkv = (size_t)c.n_fast_layer * B * c.fast_n_kv_head * c.n_fast * 64;
   s->fkc = cv.take<float>(fkv);
   s->fvc = cv.take<float>(fkv);
@@ -119,14 +123,16 @@ void carve(SmolttsSession* s, char* base, size_t* total) {
   s->stage_slots = cv.take<int>(B);
   s->stage_last = cv.take<int>(B);
   s->margin = cv.take<float>(B);
+  s->margin_at = cv.take<int>(B);
   s->codes = cv.take<int>(B * (size_t)s->max_frames * H);
   *total = cv.off;
 }
 
 __global__ void init_state_kernel(int B, int n_fast, int* iota, int* fastpos, int* pos, int* frames, int* done, int* mask,
-                                  float* margin, int* cur_col, int* new_col, int* salt) {
+                                  float* margin, int* margin_at, int* cur_col, int* new_col, int* salt) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
+  margin_at[b] = 0;
   iota[b] = b;
   for (int i = 0; i < n_fast; ++i) fastpos[i * B + b] = i;
   pos[b] = 0; frames[b] = 0; done[b] = 1; mask[b] = 0; salt[b] = 0;
@@ -177,28 +183,49 @@ __global__ void slot_park_kernel(int B, int n_slots, const int* slots, const int
     if (slots[i] == b) { pos[b] = row_pos[last_row[i]] + 1; done[b] = 1; mask[b] = 0; }
 }
 
-__global__ void decode_mask_kernel(int B, const int* done, int* mask) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < B) mask[b] = !done[b];
-}
+// End of frame (lm/generate.py:143-171) and start of the next one, one workgroup per slot:
+//  (1) commit (when `do_commit` and the slot's mask is set): publish the column, advance counters, apply the stop rule.
+//      `advance_pos`: the slow step of this frame consumed one new token (decode) vs. the prompt (prefill).  A slot also
+//      stops when its context is full (the next token would land at position max_seq: no KV row, no RoPE row for it) --
+//      the reference's torch model has the same hard limit (max_seq_len buffers, modeling/...:180-199).
+//  (2) mask = !done for the next frame (only live slots commit there);
+//  (3) embed the slot's current column as the next slow step's input row (residual stream + X3 operand + sum of squares
+//      for layer 0), so a decode frame starts with the first QKV GEMM: no separate mask / embed launches.
+// Invariant between API calls: (xt, x3n, ssq) hold the embedded current columns of all slots and mask == !done.
+struct CommitArgs {
+  int B, H, max_frames, max_seq, im_end, stop_on_eos, advance_pos, do_commit;
+  const int* new_col;
+  int *mask, *cur_col, *codes, *pos, *frames, *done;
+};
 
-// End of frame (lm/generate.py:143-171): publish the column, advance counters, apply the stop rule.
-// `advance_pos`: the slow step of this frame consumed one new token (decode) vs. the prompt (prefill).
-__global__ void commit_kernel(int B, int H, int max_frames, int im_end, int stop_on_eos, int advance_pos, const int* mask,
-                              const int* new_col, int* cur_col, int* codes, int* pos, int* frames, int* done) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B || !mask[b]) return;
-  const int f = frames[b];
-  if (advance_pos) pos[b] += 1;
-  if (f < max_frames) {
-    for (int i = 0; i < H; ++i) {
-      const int v = new_col[b * H + i];
-      cur_col[b * H + i] = v;
-      codes[((long)b * max_frames + f) * H + i] = v;
+__global__ __launch_bounds__(256) void commit_embed_kernel(CommitArgs a, EmbedTables t, float* xt, EmitDev emit) {
+  __shared__ int s_col[64];
+  __shared__ float sh4[4];
+  const int b = blockIdx.x, tid = threadIdx.x, H = a.H;  // H <= 64: the whole commit happens inside wave 0, in program order
+  int f = 0;
+  bool live = false;
+  if (tid < 64) { f = a.frames[b]; live = a.do_commit && a.mask[b]; }
+  const bool publish = live && f < a.max_frames;
+  if (tid < H) {
+    const int v = publish ? a.new_col[b * H + tid] : a.cur_col[b * H + tid];
+    s_col[tid] = v;
+    if (publish) {
+      a.cur_col[b * H + tid] = v;
+      a.codes[((long)b * a.max_frames + f) * H + tid] = v;
     }
-    frames[b] = f + 1;
   }
-  if ((stop_on_eos && new_col[b * H] == im_end) || f + 1 >= max_frames) done[b] = 1;
+  if (tid == 0) {
+    int d = a.done[b];
+    if (live) {
+      int p = a.pos[b];
+      if (a.advance_pos) a.pos[b] = ++p;
+      if (publish) a.frames[b] = f + 1;
+      if ((a.stop_on_eos && a.new_col[b * H] == a.im_end) || f + 1 >= a.max_frames || p >= a.max_seq) a.done[b] = d = 1;
+    }
+    a.mask[b] = !d;
+  }
+  __syncthreads();
+  embed_row(t, s_col, b, xt, emit, sh4);
 }
 
 // `fmt` = the engine's weight_format; an fp8 matrix is its tiles (N*K bytes, N % 16 == 0) followed by N row scales
@@ -211,11 +238,23 @@ SmolttsGemm3Args base3(int fmt, const void* w, const void* x3, int M, int N, int
   return a;
 }
 
+// Measurement aid (smoltts_session_measure_duplicate): kernel classes are named by their GEMM epilogue (+ N), or
+// 100 = short-cache (depth) attention, 101 = long-cache (slow) attention.  Only idempotent launches can be doubled
+// (EPI_RESID accumulates into its own input).
+bool dup_hit(const SmolttsSession* s, int code, int N) { return s->dup_code == code && (s->dup_n <= 0 || s->dup_n == N); }
+
+int launch_gemm3_m(const SmolttsSession* s, const SmolttsGemm3Args& a, hipStream_t st) {
+  ST_TRY(launch_gemm3(a, st));
+  if (a.epilogue != SMOLTTS_EPI_RESID && dup_hit(s, a.epilogue, a.N)) ST_TRY(launch_gemm3(a, st));
+  return SMOLTTS_OK;
+}
+
 // One pre-norm block (modeling/model/rq_transformer.py:492-501) over `M` rows of the fp32 stream x (in place).
 // `in_x3`/ssq: x published for the wqkv GEMM by whoever produced x; `next`: where the block publishes its output.
 int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, int n_head, int n_kv, int inter, float* x,
-              float* q, int M, const int* row_pos, const int* row_slot, const float* rope, float* kc, float* vc,
-              int cache_len, const char* in_x3, const EmitArgs& next, hipStream_t st, bool first_pos = false) {
+              float* q, int M, const int* row_pos, const int* row_slot, const float* rope, void* kc, void* vc,
+              int cache_len, const char* in_x3, const EmitArgs& next, hipStream_t st, bool first_pos = false,
+              int kv_format = SMOLTTS_KV_F32) {
   // first_pos: every row is at position 0 (depth step 0), so attention over its single key is the row's own V: the QKV
   // epilogue publishes V as wo's operand and the attention launch is skipped.
   const SmolttsEngine* e = s->e;
@@ -225,11 +264,16 @@ int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, i
     SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.wqkv, in_x3, M, (n_head + 2 * n_kv) * 64, dim, SMOLTTS_EPI_QKV_ROPE);
     a.ssq_in_dev = s->ssq; a.eps = eps; a.out_dev = q; a.ldo = n_head * 64;
     a.rope_dev = rope; a.row_pos_dev = row_pos; a.row_slot_dev = row_slot;
-    a.k_cache_dev = kc; a.v_cache_dev = vc; a.n_q_heads = n_head; a.n_kv_heads = n_kv; a.cache_len = cache_len;
+    a.k_cache_dev = (float*)kc; a.v_cache_dev = (float*)vc; a.n_q_heads = n_head; a.n_kv_heads = n_kv; a.cache_len = cache_len;
+    a.kv_format = kv_format;
     if (first_pos) a.v_x3_dev = s->x3a;
-    ST_TRY(launch_gemm3(a, st));
+    ST_TRY(launch_gemm3_m(s, a, st));
   }
-  if (!first_pos) ST_TRY(launch_attention(q, kc, vc, row_pos, row_slot, M, n_head, n_kv, cache_len, 0, nullptr, s->x3a, st));
+  if (!first_pos) {
+    const int reps = dup_hit(s, cache_len <= 16 ? 100 : 101, 0) ? 2 : 1;
+    for (int i = 0; i < reps; ++i)
+      ST_TRY(launch_attention(q, kc, vc, row_pos, row_slot, M, n_head, n_kv, cache_len, 0, nullptr, s->x3a, st, kv_format));
+  }
   {  // x += attn . Wo^T ; publish x * ffn_norm for w1|w3
     SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.wo, s->x3a, M, dim, dim, SMOLTTS_EPI_RESID);
     a.resid_dev = x; a.out_dev = x; a.ldo = dim;
@@ -239,7 +283,7 @@ int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, i
   {  // h = silu(w1 n) * (w3 n), n = RMSNorm(x); written as w2's operand
     SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.w13, s->x3n, M, 2 * inter, dim, SMOLTTS_EPI_SWIGLU);
     a.ssq_in_dev = s->ssq; a.eps = eps; a.x3_out_dev = s->x3h;
-    ST_TRY(launch_gemm3(a, st));
+    ST_TRY(launch_gemm3_m(s, a, st));
   }
   {  // x += h . W2^T ; publish for the next consumer(s)
     SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.w2, s->x3h, M, dim, inter, SMOLTTS_EPI_RESID);
@@ -271,6 +315,27 @@ __global__ __launch_bounds__(256) void scatter_last_kernel(const float* xr, cons
     *reinterpret_cast<float4*>(xt + dst * dim + d) = *reinterpret_cast<const float4*>(xr + src * dim + d);
 }
 
+EmbedTables embed_tables(const SmolttsEngine* e) {
+  const SmolttsLMConfig& c = e->cfg;
+  const char* A = e->arena;
+  return EmbedTables{(const uint16_t*)(A + e->w.text_emb), (const uint16_t*)(A + e->w.codebook_emb), c.dim, c.codebook_size,
+                     c.duplicate_code_0 ? 0 : c.codebook_size, c.embed_mask_mode, c.semantic_start_id, c.semantic_end_id,
+                     c.vocab_size, c.codebook_size * c.num_codebooks, c.n_fast};
+}
+
+// commit (optional) + next-frame mask + embedding of every slot's current column (see commit_embed_kernel)
+int launch_commit_embed(SmolttsSession* s, int do_commit, int advance_pos, hipStream_t st) {
+  const SmolttsEngine* e = s->e;
+  const SmolttsLMConfig& c = e->cfg;
+  ST_REQUIRE(1 + c.n_fast <= 64 && c.dim % 64 == 0, SMOLTTS_E_INVALID, "commit: grid height > 64 or dim %% 64 != 0");
+  const CommitArgs a{s->B, 1 + c.n_fast, s->max_frames, s->max_seq, c.im_end_id, s->stop_on_eos, advance_pos, do_commit,
+                     s->new_col, s->mask, s->cur_col, s->codes, s->pos, s->frames, s->done};
+  const EmitDev em{s->x3n, gamma_at(e, e->w.layers[0].attn_norm), nullptr, nullptr, s->ssq};
+  hipLaunchKernelGGL(commit_embed_kernel, dim3(s->B), dim3(256), 0, st, a, embed_tables(e), s->xt, em);
+  ST_CHECK_HIP(hipGetLastError());
+  return SMOLTTS_OK;
+}
+
 // Slow head + the depth transformer for all B slots; columns land in new_col, commit applies `mask`.
 // Precondition: xt holds the pre-norm slow hidden and has been published via slow_hidden_emit().
 int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
@@ -281,9 +346,9 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
   {  // logits = RMSNorm(x) . E^T   (lm/rq_transformer.py:184-189)
     SmolttsGemm3Args a = base3(c.weight_format, A + e->w.head, s->x3n, B, c.vocab_size, c.dim, SMOLTTS_EPI_STORE);
     a.ssq_in_dev = s->ssq; a.eps = c.norm_eps; a.out_dev = s->logits; a.ldo = c.vocab_size;
-    ST_TRY(launch_gemm3(a, st));
+    ST_TRY(launch_gemm3_m(s, a, st));
   }
-  const SampleArgs slow_sa{s->temp, s->min_p, s->seed, 0, 0, s->frames, s->salt};
+  const SampleArgs slow_sa{s->temp, s->min_p, s->seed, 0, 0, s->frames, s->salt, s->margin_at};
   ST_TRY(launch_argmax(s->logits, B, c.vocab_size, c.vocab_size, s->new_col, H, s->margin, s->mask, nullptr, 0, 0, nullptr,
                        nullptr, &slow_sa, st));
   float* xf = s->xt;  // fast input = pre-norm slow hidden (lm/rq_transformer.py:191)
@@ -312,21 +377,18 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
       const size_t wbytes = c.weight_format == SMOLTTS_W_FP8 ? wrow * (c.fast_dim + 4) : wrow * c.fast_dim * 2;
       SmolttsGemm3Args a = base3(c.weight_format, A + e->w.fast_head + wbytes, s->x3n, B, c.codebook_size, c.fast_dim, SMOLTTS_EPI_STORE);
       a.ssq_in_dev = s->ssq; a.eps = c.norm_eps; a.out_dev = s->logits; a.ldo = c.codebook_size;
-      ST_TRY(launch_gemm3(a, st));
+      ST_TRY(launch_gemm3_m(s, a, st));
     }
     const bool more = i + 1 < c.n_fast;
     const int off = c.depthwise_wte ? (c.duplicate_code_0 ? i : i + 1) * c.codebook_size : 0;  // generate.py:136-140
     float* xnext = c.has_fast_project_in ? s->xf : s->xt;
-    const SampleArgs fast_sa{s->fast_temp, s->fast_temp > 0.f ? s->min_p : 0.f, s->seed, 1 + i, 0, s->frames, s->salt};
+    const SampleArgs fast_sa{s->fast_temp, s->fast_temp > 0.f ? s->min_p : 0.f, s->seed, 1 + i, 0, s->frames, s->salt, s->margin_at};
     ST_TRY(launch_argmax(s->logits, B, c.codebook_size, c.codebook_size, s->new_col + 1 + i, H, s->margin, s->mask,
                          more ? (const void*)(A + e->w.fast_emb) : nullptr, off, c.fast_dim, more ? xnext : nullptr,
                          more ? &to_fast0 : nullptr, &fast_sa, st));
     xf = xnext;
   }
-  hipLaunchKernelGGL(commit_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, H, s->max_frames, c.im_end_id, s->stop_on_eos,
-                     advance_pos, s->mask, s->new_col, s->cur_col, s->codes, s->pos, s->frames, s->done);
-  ST_CHECK_HIP(hipGetLastError());
-  return SMOLTTS_OK;
+  return launch_commit_embed(s, /*do_commit=*/1, advance_pos, st);
 }
 
 // Slow transformer over M rows of x (already embedded and published for layer 0).
@@ -334,13 +396,14 @@ int run_slow_layers(SmolttsSession* s, float* x, float* q, int M, const int* row
                     hipStream_t st) {
   const SmolttsEngine* e = s->e;
   const SmolttsLMConfig& c = e->cfg;
-  const size_t l_stride = (size_t)s->B * c.n_kv_head * s->max_seq * 64;
+  const size_t l_stride = (size_t)s->B * c.n_kv_head * s->max_seq * 64 * (s->kv_format == SMOLTTS_KV_BF16 ? 2 : 4);  // bytes
   for (int l = 0; l < c.n_layer; ++l) {
     EmitArgs next{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (l + 1 < c.n_layer) next = EmitArgs{s->x3n, gamma_at(e, e->w.layers[l + 1].attn_norm), nullptr, nullptr, s->ssq};
     else if (publish_hidden) next = slow_hidden_emit(s);
     ST_TRY(run_block(s, e->w.layers[l], c.dim, c.n_head, c.n_kv_head, c.inter, x, q, M, row_pos, row_slot,
-                     (const float*)(e->arena + e->w.rope), s->kc + l * l_stride, s->vc + l * l_stride, s->max_seq, s->x3n, next, st));
+                     (const float*)(e->arena + e->w.rope), s->kc + l * l_stride, s->vc + l * l_stride, s->max_seq, s->x3n, next, st,
+                     /*first_pos=*/false, s->kv_format));
   }
   return SMOLTTS_OK;
 }
@@ -356,12 +419,9 @@ int embed_rows(SmolttsSession* s, const int* cols, int M, float* x, hipStream_t 
                       x, &em, st);
 }
 
+// One decode frame.  Precondition (the session invariant): xt / x3n / ssq hold the embedded current columns, mask == !done.
 int run_decode_frame(SmolttsSession* s, hipStream_t st) {
-  const int B = s->B;
-  hipLaunchKernelGGL(decode_mask_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, s->done, s->mask);
-  ST_CHECK_HIP(hipGetLastError());
-  ST_TRY(embed_rows(s, s->cur_col, B, s->xt, st));
-  ST_TRY(run_slow_layers(s, s->xt, s->qt, B, s->pos, s->iota, /*publish_hidden=*/true, st));
+  ST_TRY(run_slow_layers(s, s->xt, s->qt, s->B, s->pos, s->iota, /*publish_hidden=*/true, st));
   return run_tail(s, /*advance_pos=*/1, st);
 }
 
@@ -484,10 +544,17 @@ void smoltts_engine_destroy(SmolttsEngine* e) { delete e; }
 
 size_t smoltts_session_slab_bytes(const SmolttsEngine* e, int32_t max_batch, int32_t max_seq, int32_t max_rows,
                                   int32_t max_frames) {
+  return smoltts_session_slab_bytes_kv(e, max_batch, max_seq, max_rows, max_frames, SMOLTTS_KV_F32);
+}
+
+size_t smoltts_session_slab_bytes_kv(const SmolttsEngine* e, int32_t max_batch, int32_t max_seq, int32_t max_rows,
+                                     int32_t max_frames, int32_t kv_format) {
   if (!e || max_batch <= 0 || max_seq <= 0 || max_rows <= 0 || max_frames <= 0) return 0;
+  if (kv_format != SMOLTTS_KV_F32 && kv_format != SMOLTTS_KV_BF16) return 0;
   SmolttsSession tmp;
   memset(&tmp, 0, sizeof(tmp));
   tmp.e = const_cast<SmolttsEngine*>(e);
+  tmp.kv_format = kv_format;
   tmp.B = max_batch; tmp.max_seq = max_seq; tmp.max_rows = max_rows; tmp.max_frames = max_frames;
   size_t total = 0;
   carve(&tmp, nullptr, &total);
@@ -496,17 +563,26 @@ size_t smoltts_session_slab_bytes(const SmolttsEngine* e, int32_t max_batch, int
 
 int smoltts_session_create(SmolttsEngine* e, void* slab_dev, size_t slab_bytes, int32_t max_batch, int32_t max_seq,
                            int32_t max_rows, int32_t max_frames, SmolttsSession** out) {
+  return smoltts_session_create_kv(e, slab_dev, slab_bytes, max_batch, max_seq, max_rows, max_frames, SMOLTTS_KV_F32, out);
+}
+
+int smoltts_session_create_kv(SmolttsEngine* e, void* slab_dev, size_t slab_bytes, int32_t max_batch, int32_t max_seq,
+                              int32_t max_rows, int32_t max_frames, int32_t kv_format, SmolttsSession** out) {
   ST_REQUIRE(e && slab_dev && out, SMOLTTS_E_INVALID, "session_create: null argument");
+  ST_REQUIRE(kv_format == SMOLTTS_KV_F32 || kv_format == SMOLTTS_KV_BF16, SMOLTTS_E_INVALID, "session_create: unknown kv_format %d", kv_format);
+  ST_REQUIRE(kv_format == SMOLTTS_KV_F32 || max_seq > 16, SMOLTTS_E_INVALID, "session_create: a bf16 KV cache needs max_seq > 16");
   ST_REQUIRE(max_batch > 0 && max_batch <= 4096 && max_rows > 0 && max_frames > 0, SMOLTTS_E_INVALID, "session_create: bad sizes");
   ST_REQUIRE(max_seq > 0 && max_seq <= e->cfg.max_seq_len, SMOLTTS_E_CAPACITY,
              "session_create: max_seq %d exceeds the RoPE table (%d)", max_seq, e->cfg.max_seq_len);
   ST_REQUIRE(((uintptr_t)slab_dev & 255) == 0, SMOLTTS_E_INVALID, "session_create: slab must be 256-byte aligned");
-  const size_t need = smoltts_session_slab_bytes(e, max_batch, max_seq, max_rows, max_frames);
+  const size_t need = smoltts_session_slab_bytes_kv(e, max_batch, max_seq, max_rows, max_frames, kv_format);
   ST_REQUIRE(slab_bytes >= need, SMOLTTS_E_CAPACITY, "session_create: slab has %zu bytes, %zu needed", slab_bytes, need);
   SmolttsSession* s = new (std::nothrow) SmolttsSession;
   ST_REQUIRE(s, SMOLTTS_E_INVALID, "session_create: out of host memory");
   memset(s, 0, sizeof(*s));
   s->e = e; s->B = max_batch; s->max_seq = max_seq; s->max_rows = max_rows; s->max_frames = max_frames;
+  s->dup_code = -1;
+  s->kv_format = kv_format;
   size_t total = 0;
   carve(s, (char*)slab_dev, &total);
   if (hipHostMalloc((void**)&s->h_stage, sizeof(int) * 2 * max_batch * STAGE_RING, hipHostMallocDefault) != hipSuccess) {
@@ -524,7 +600,7 @@ int smoltts_session_create(SmolttsEngine* e, void* slab_dev, size_t slab_bytes, 
     }
   }
   hipLaunchKernelGGL(init_state_kernel, dim3((max_batch + 63) / 64), dim3(64), 0, 0, max_batch, e->cfg.n_fast, s->iota,
-                     s->fastpos, s->pos, s->frames, s->done, s->mask, s->margin, s->cur_col, s->new_col, s->salt);
+                     s->fastpos, s->pos, s->frames, s->done, s->mask, s->margin, s->margin_at, s->cur_col, s->new_col, s->salt);
   hipError_t err = hipGetLastError();
   if (err == hipSuccess) err = hipStreamSynchronize(0);
   if (err != hipSuccess) {
@@ -606,7 +682,8 @@ int smoltts_lm_prefill_chunk(SmolttsSession* s, const int32_t* grid_dev, const i
                      s->pos, s->done, s->mask);
   ST_CHECK_HIP(hipGetLastError());
   ST_TRY(embed_rows(s, grid_dev, n_rows, s->xr, st));
-  return run_slow_layers(s, s->xr, s->qr, n_rows, row_pos_dev, row_slot_dev, /*publish_hidden=*/false, st);
+  ST_TRY(run_slow_layers(s, s->xr, s->qr, n_rows, row_pos_dev, row_slot_dev, /*publish_hidden=*/false, st));
+  return launch_commit_embed(s, /*do_commit=*/0, 0, st);  // the prompt rows went through x3n / ssq: re-publish the decode rows
 }
 
 int smoltts_lm_prefill_deferred(SmolttsSession* s, const int32_t* grid_dev, const int32_t* row_slot_dev, const int32_t* row_pos_dev,
@@ -630,6 +707,7 @@ int smoltts_lm_prefill_deferred(SmolttsSession* s, const int32_t* grid_dev, cons
   hipLaunchKernelGGL(slot_start_kernel, dim3((s->B + 63) / 64), dim3(64), 0, st, s->B, 1 + s->e->cfg.n_fast, n_slots, s->stage_slots,
                      s->stage_last, row_pos_dev, grid_dev, s->pos, s->frames, s->done, s->margin, s->cur_col, s->salt);
   ST_CHECK_HIP(hipGetLastError());
+  ST_TRY(launch_commit_embed(s, /*do_commit=*/0, 0, st));  // mask = !done; embed every slot's (new) current column
   s->prefilled = true;
   return SMOLTTS_OK;
 }
@@ -662,6 +740,17 @@ int smoltts_session_set_sampling(SmolttsSession* s, float temp, float fast_temp,
   return SMOLTTS_OK;
 }
 
+// Measurement aid of this session only: while code >= 0, every launch of that kernel class inside this session's frames
+// (GEMM epilogue code, N == n_filter when n_filter > 0; 100 / 101 = depth / slow attention) is issued twice; the captured
+// graphs are dropped.  (t_dup - t_base) / extra launches is the kernel's duration in situ.
+int smoltts_session_measure_duplicate(SmolttsSession* s, int32_t code, int32_t n_filter) {
+  ST_REQUIRE(s, SMOLTTS_E_INVALID, "session_measure_duplicate: null session");
+  ST_REQUIRE(code != SMOLTTS_EPI_RESID, SMOLTTS_E_INVALID, "session_measure_duplicate: EPI_RESID launches are not idempotent");
+  s->dup_code = code; s->dup_n = n_filter;
+  drop_graphs(s);
+  return SMOLTTS_OK;
+}
+
 // Forget the captured frame graph (the next smoltts_lm_decode captures it again).
 int smoltts_session_drop_graph(SmolttsSession* s) {
   ST_REQUIRE(s, SMOLTTS_E_INVALID, "session_drop_graph: null session");
@@ -676,6 +765,12 @@ int smoltts_session_outputs(SmolttsSession* s, int32_t** codes_dev, int32_t** n_
   if (n_frames_dev) *n_frames_dev = s->frames;
   if (done_dev) *done_dev = s->done;
   if (margin_dev) *margin_dev = s->margin;
+  return SMOLTTS_OK;
+}
+
+int smoltts_session_margin_at(SmolttsSession* s, int32_t** margin_at_dev) {
+  ST_REQUIRE(s && margin_at_dev, SMOLTTS_E_INVALID, "session_margin_at: null argument");
+  *margin_at_dev = s->margin_at;
   return SMOLTTS_OK;
 }
 

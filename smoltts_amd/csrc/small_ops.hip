@@ -1,42 +1,20 @@
 // Gather / reduce operators around the GEMMs: token embedding, greedy argmax (+ next-step
 // embedding gather), LayerNorm, row gather.  All are HBM/L2-bound byte movers: one workgroup per
 // row, 16-byte (fp32) / 8-byte (bf16x4) accesses per lane, fixed-order reductions.
-#include "x3.h"
+#include "embed_dev.h"
 
 namespace smoltts {
 
 // ------------------------------------------------------------------------------------ embed
-// x[r] = E_text[cols[r][0]] + keep * sum_k E_cb[cols[r][1+k] + cb_first_offset + k*codebook_size]
-// reference: BaseTransformer.embed (modeling/model/rq_transformer.py:205-221); MLX twin
-// lm/rq_transformer.py:150-170 (mask rule differs: mask_mode 1).
+// (row body: embed_row in embed_dev.h, shared with the frame loop's commit kernel)
 __global__ __launch_bounds__(256) void embed_kernel(const int* cols, int n_code_rows, const uint16_t* text_emb,
                                                     const uint16_t* cb_emb, int dim, int codebook_size,
                                                     int cb_first_offset, int mask_mode, int sem_start, int sem_end,
                                                     int text_rows, int cb_rows, float* x, EmitDev emit) {
   __shared__ float sh4[4];
-  float ss = 0.f;
   const int r = blockIdx.x;
-  const int* c = cols + (long)r * (1 + n_code_rows);
-  int tok = c[0];
-  tok = tok < 0 ? 0 : (tok >= text_rows ? text_rows - 1 : tok);  // never read outside the table
-  const bool keep = mask_mode == 0 ? (c[1] != 0) : (tok >= sem_start && tok <= sem_end);
-  for (int d = threadIdx.x * 4; d < dim; d += blockDim.x * 4) {
-    const uint2 t = *reinterpret_cast<const uint2*>(text_emb + (long)tok * dim + d);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (keep) {
-      for (int k = 0; k < n_code_rows; ++k) {  // same summation order as vq_embeds.sum(dim=1)
-        long row = (long)c[1 + k] + cb_first_offset + (long)k * codebook_size;
-        row = row < 0 ? 0 : (row >= cb_rows ? cb_rows - 1 : row);
-        const uint2 e = *reinterpret_cast<const uint2*>(cb_emb + row * dim + d);
-        acc.x += bf16_lo(e.x); acc.y += bf16_hi(e.x); acc.z += bf16_lo(e.y); acc.w += bf16_hi(e.y);
-      }
-    }
-    const float4 o = make_float4(bf16_lo(t.x) + acc.x, bf16_hi(t.x) + acc.y, bf16_lo(t.y) + acc.z, bf16_hi(t.y) + acc.w);
-    *reinterpret_cast<float4*>(x + (long)r * dim + d) = o;
-    ss += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
-    emit_x4(emit, r, d, dim >> 5, o.x, o.y, o.z, o.w);
-  }
-  emit_row_ssq(emit, r, dim, ss, sh4);
+  const EmbedTables t{text_emb, cb_emb, dim, codebook_size, cb_first_offset, mask_mode, sem_start, sem_end, text_rows, cb_rows, n_code_rows};
+  embed_row(t, cols + (long)r * (1 + n_code_rows), r, x, emit, sh4);
 }
 
 int launch_embed(const int32_t* cols, int n_rows, int n_code_rows, const void* text_emb, const void* cb_emb, int dim,
@@ -146,7 +124,13 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int n_
   if (tid == 0) {
     if (a.i1 < 0 || a.i1 >= n_cols) a.i1 = 0;  // all-NaN row: stay inside the tables
     ids[(long)r * ids_stride] = a.i1;
-    if (sa.temp <= 0.f && margin && (margin_mask == nullptr || margin_mask[r])) margin[r] = fminf(margin[r], a.v1 - a.v2);
+    if (sa.temp <= 0.f && margin && (margin_mask == nullptr || margin_mask[r])) {
+      const float gap = a.v1 - a.v2;
+      if (gap < margin[r]) {  // also remember where the slot's smallest gap occurred: frame * 64 + step (0 = slow id)
+        margin[r] = gap;
+        if (sa.margin_at) sa.margin_at[r] = (sa.frames ? sa.frames[r] : sa.frame_base + r) * 64 + sa.step;
+      }
+    }
     s_id = a.i1;
   }
   if (emb == nullptr) return;
@@ -166,7 +150,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int n_
 int launch_argmax(const float* logits, int n_rows, int n_cols, int64_t ld, int32_t* ids, int ids_stride, float* margin,
                   const int32_t* margin_mask, const void* emb, int emb_row_offset, int dim, float* xnext,
                   const EmitArgs* emit, const SampleArgs* sample, hipStream_t stream) {
-  SampleArgs sa{0.f, 0.f, 0, 0, 0, nullptr, nullptr};
+  SampleArgs sa{0.f, 0.f, 0, 0, 0, nullptr, nullptr, nullptr};
   if (sample) sa = *sample;
   EmitDev e{nullptr, nullptr, nullptr, nullptr, nullptr};
   if (emit && emb) e = EmitDev{(char*)emit->x3a, emit->gamma_a, (char*)emit->x3b, emit->gamma_b, emit->ssq};

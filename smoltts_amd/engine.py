@@ -7,6 +7,8 @@ every wrapper raises ``SmolttsError`` on a non-zero status.
 from __future__ import annotations
 
 import ctypes as C
+import os
+import sys
 from pathlib import Path
 from typing import Dict, List, Optional, Sequence
 
@@ -86,6 +88,7 @@ class MimiEncWeights(C.Structure):
 
 
 PRO_NONE, PRO_RMSNORM, PRO_ELU = 0, 1, 2
+KV_FORMATS = {"fp32": 0, "bf16": 1}  # SMOLTTS_KV_*
 EPI_STORE, EPI_RESID, EPI_SWIGLU, EPI_GELU, EPI_SCALE_RESID, EPI_QKV_ROPE = range(6)
 
 _lib = None
@@ -96,8 +99,9 @@ _EXPORTS = [
     "smoltts_lm_decode", "smoltts_session_outputs", "smoltts_mimi_create", "smoltts_mimi_destroy",
     "smoltts_mimi_slab_bytes", "smoltts_mimi_session_create", "smoltts_mimi_session_destroy", "smoltts_mimi_reset",
     "smoltts_mimi_decode_chunk", "smoltts_k_gemm", "smoltts_k_attention", "smoltts_k_embed", "smoltts_k_argmax",
-    "smoltts_k_layernorm", "smoltts_profile_begin", "smoltts_profile_end", "smoltts_k_gemm3", "smoltts_k_x3_pack",
-    "smoltts_debug_duplicate", "smoltts_session_drop_graph", "smoltts_session_set_sampling", "smoltts_k_sample",
+    "smoltts_k_layernorm", "smoltts_k_gemm3", "smoltts_k_x3_pack",
+    "smoltts_session_measure_duplicate", "smoltts_session_margin_at", "smoltts_session_drop_graph",
+    "smoltts_session_slab_bytes_kv", "smoltts_session_create_kv", "smoltts_k_attention_kv", "smoltts_session_set_sampling", "smoltts_k_sample",
     "smoltts_lm_prefill_chunk", "smoltts_lm_prefill_deferred", "smoltts_mimi_reset_slots", "smoltts_mimi_encoder_create", "smoltts_mimi_encoder_destroy", "smoltts_mimi_encode_frames",
     "smoltts_mimi_encode_workspace_bytes", "smoltts_mimi_encode",
 ]
@@ -112,7 +116,10 @@ def load_library(path: Optional[Path] = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = Path(path) if path is not None else LIB_PATH
+    override = os.environ.get("SMOLTTS_LIB")  # tools/ A/B runs: a variant built by `python -m smoltts_amd.build --variant ...`
+    if path is None and override:
+        print(f"[smoltts_amd] loading the library VARIANT {override} (SMOLTTS_LIB is set): not the product build", file=sys.stderr, flush=True)
+    p = Path(path) if path is not None else (Path(override) if override else LIB_PATH)
     if not p.exists():
         raise SmolttsError(
             f"{p} not found: build it with `python -m smoltts_amd.build` (hipcc, gfx950). "
@@ -123,6 +130,11 @@ def load_library(path: Optional[Path] = None):
     lib.smoltts_session_slab_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.smoltts_mimi_slab_bytes.restype = C.c_size_t
     lib.smoltts_mimi_slab_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.smoltts_session_slab_bytes_kv.restype = C.c_size_t
+    lib.smoltts_session_slab_bytes_kv.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.smoltts_session_create_kv.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                              C.POINTER(C.c_void_p)]
+    lib.smoltts_k_attention_kv.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.smoltts_engine_create.argtypes = [C.POINTER(LMConfig), C.POINTER(LMWeights), C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
     lib.smoltts_engine_destroy.argtypes = [C.c_void_p]
     lib.smoltts_engine_destroy.restype = None
@@ -148,7 +160,8 @@ def load_library(path: Optional[Path] = None):
     lib.smoltts_session_set_sampling.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_uint64]
     lib.smoltts_k_sample.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_uint64, C.c_int32,
                                      C.c_int32, C.c_void_p, C.c_void_p]
-    lib.smoltts_debug_duplicate.argtypes = [C.c_int32, C.c_int32]
+    lib.smoltts_session_measure_duplicate.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.smoltts_session_margin_at.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     lib.smoltts_session_drop_graph.argtypes = [C.c_void_p]
     lib.smoltts_mimi_reset_slots.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.smoltts_lm_prefill_deferred.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
@@ -164,8 +177,9 @@ def load_library(path: Optional[Path] = None):
     lib.smoltts_mimi_encode_workspace_bytes.restype = C.c_size_t
     lib.smoltts_mimi_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                         C.c_void_p]
-    lib.smoltts_profile_begin.argtypes = [C.c_int32] * 4
-    lib.smoltts_profile_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    if hasattr(lib, "smoltts_profile_begin"):  # diagnostic builds only (-DSMOLTTS_DEBUG_HOOKS)
+        lib.smoltts_profile_begin.argtypes = [C.c_int32] * 4
+        lib.smoltts_profile_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     if lib.smoltts_abi_version() != 1:
         raise SmolttsError("libsmoltts_hip.so ABI version mismatch")
     if path is None:
@@ -324,20 +338,26 @@ class LMSession:
     """B utterance slots (KV caches + device-side frame loop state) inside one device slab."""
 
     def __init__(self, engine: LMEngine, max_batch: int, max_seq: Optional[int] = None, max_rows: int = 4096,
-                 max_frames: int = 1025):
+                 max_frames: int = 1025, kv_dtype: str = "fp32"):
+        """``kv_dtype="bf16"``: the slow transformer's KV cache holds K (after RoPE) and V rounded to bf16 (half the
+        attention stream; the oracle's ``kv_bf16=True`` is the same arithmetic).  Default fp32: K/V exactly as computed."""
+        if kv_dtype not in KV_FORMATS:
+            raise ValueError(f"kv_dtype must be one of {sorted(KV_FORMATS)}, got {kv_dtype!r}")
+        self.kv_dtype = kv_dtype
+        kvf = KV_FORMATS[kv_dtype]
         self.engine, self.lib = engine, engine.lib
         self.B = max_batch
         self.max_seq = max_seq or engine.cfg.max_seq_len
         self.max_rows = max(max_rows, max_batch)
         self.max_frames = max_frames
         self.H = engine.grid_height
-        need = self.lib.smoltts_session_slab_bytes(engine.handle, self.B, self.max_seq, self.max_rows, self.max_frames)
+        need = self.lib.smoltts_session_slab_bytes_kv(engine.handle, self.B, self.max_seq, self.max_rows, self.max_frames, kvf)
         if need == 0:
             raise SmolttsError("smoltts_session_slab_bytes returned 0 (bad sizes)")
         self.slab = _alloc_slab(need, engine.device)
         h = C.c_void_p()
-        check(self.lib.smoltts_session_create(engine.handle, dptr(self.slab), need, self.B, self.max_seq, self.max_rows,
-                                              self.max_frames, C.byref(h)), "smoltts_session_create")
+        check(self.lib.smoltts_session_create_kv(engine.handle, dptr(self.slab), need, self.B, self.max_seq, self.max_rows,
+                                                 self.max_frames, kvf, C.byref(h)), "smoltts_session_create")
         self.handle = h
         ptrs = [C.c_void_p() for _ in range(4)]
         check(self.lib.smoltts_session_outputs(h, *[C.byref(p) for p in ptrs]), "smoltts_session_outputs")
@@ -351,6 +371,9 @@ class LMSession:
         self.n_frames = view(ptrs[1], self.B * 4, torch.int32, (self.B,))
         self.done = view(ptrs[2], self.B * 4, torch.int32, (self.B,))
         self.margin = view(ptrs[3], self.B * 4, torch.float32, (self.B,))
+        mp = C.c_void_p()
+        check(self.lib.smoltts_session_margin_at(h, C.byref(mp)), "smoltts_session_margin_at")
+        self.margin_at = view(mp, self.B * 4, torch.int32, (self.B,))  # frame * 64 + step of each slot's smallest gap
         self._keep = None
 
     def prefill(self, prompts: Sequence[np.ndarray], slots: Optional[Sequence[int]] = None, stop_on_eos: bool = True,
@@ -421,6 +444,10 @@ class LMSession:
         """temp / fast_temp <= 0: greedy (default). Takes effect from the next frame."""
         check(self.lib.smoltts_session_set_sampling(self.handle, float(temp), float(fast_temp), float(min_p), int(seed) & (2**64 - 1)),
               "smoltts_session_set_sampling")
+
+    def measure_duplicate(self, code: int = -1, n_filter: int = 0) -> None:
+        """Measurement aid (this session only): issue every launch of one kernel class twice; -1 switches it off."""
+        check(self.lib.smoltts_session_measure_duplicate(self.handle, int(code), int(n_filter)), "smoltts_session_measure_duplicate")
 
     def decode(self, n_frames: int) -> None:
         check(self.lib.smoltts_lm_decode(self.handle, int(n_frames), current_stream_ptr()), "smoltts_lm_decode")

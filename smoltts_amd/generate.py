@@ -9,7 +9,8 @@ stop rule) runs on the GPU inside ``smoltts_lm_decode`` and the host only fetche
 
 Sampling follows the reference's rules (lm/generate.py:88-99,118-132): the slow token is greedy iff
 ``default_temp == 0``; the depth tokens are sampled iff ``default_fast_temp`` is set and > 0; ``min_p``
-(lm/utils/samplers.py:8-34) restricts the candidates.  It runs on the device with a counter-based
+(lm/utils/samplers.py:8-34) follows ``GenerationSettings.min_p_mode``: "reference" (default) removes nothing, as the
+reference's code does; "intended" keeps tokens with p >= min_p * p_max.  It runs on the device with a counter-based
 generator keyed by ``GenerationSettings.seed`` (reproducible for a fixed seed; the reference's MLX
 generator is not reproducible across processes, so parity for the sampled modes is statistical).
 """
@@ -39,7 +40,7 @@ def _apply_sampling(session: LMSession, settings: GenerationSettings) -> None:
         import os
 
         seed = int.from_bytes(os.urandom(8), "little")
-    session.set_sampling(temp=settings.default_temp, fast_temp=max(fast, 0.0), min_p=settings.min_p or 0.0, seed=seed)
+    session.set_sampling(temp=settings.default_temp, fast_temp=max(fast, 0.0), min_p=settings.effective_min_p, seed=seed)
 
 
 def _frame_to_token(engine: LMEngine, col: np.ndarray) -> VQToken:

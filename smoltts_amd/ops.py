@@ -59,13 +59,14 @@ def linear(x: torch.Tensor, w_tiles: torch.Tensor, N: int, *, w_fp32: bool = Fal
 
 def attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, row_pos: torch.Tensor,
               row_slot: torch.Tensor, n_q_heads: int, window: int = 0, out_x3: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q [rows, Hq*64]; caches [slots, KV, cache_len, 64]; -> [rows, Hq*64] (and the X3 operand if given)."""
+    """q [rows, Hq*64]; caches [slots, KV, cache_len, 64] fp32 or bf16; -> [rows, Hq*64] (and the X3 operand if given)."""
     lib = E.load_library()
     n_kv, cache_len = k_cache.shape[1], k_cache.shape[2]
+    assert k_cache.dtype == v_cache.dtype and k_cache.dtype in (torch.float32, torch.bfloat16)
     out = torch.empty_like(q)
-    E.check(lib.smoltts_k_attention(E.dptr(q), E.dptr(k_cache), E.dptr(v_cache), E.dptr(row_pos), E.dptr(row_slot),
-                                    q.shape[0], n_q_heads, n_kv, cache_len, window, E.dptr(out), E.dptr(out_x3),
-                                    E.current_stream_ptr()), "smoltts_k_attention")
+    E.check(lib.smoltts_k_attention_kv(E.dptr(q), E.dptr(k_cache), E.dptr(v_cache), E.dptr(row_pos), E.dptr(row_slot),
+                                       q.shape[0], n_q_heads, n_kv, cache_len, window, E.dptr(out), E.dptr(out_x3),
+                                       1 if k_cache.dtype == torch.bfloat16 else 0, E.current_stream_ptr()), "smoltts_k_attention_kv")
     return out
 
 
@@ -137,6 +138,7 @@ class Gemm3Args(C.Structure):
         ("ssq_out_dev", C.c_void_p), ("rope_dev", C.c_void_p), ("row_pos_dev", C.c_void_p), ("row_slot_dev", C.c_void_p),
         ("k_cache_dev", C.c_void_p), ("v_cache_dev", C.c_void_p), ("n_q_heads", C.c_int32), ("n_kv_heads", C.c_int32),
         ("cache_len", C.c_int32), ("w_format", C.c_int32), ("w_scale_dev", C.c_void_p), ("v_x3_dev", C.c_void_p),
+        ("kv_format", C.c_int32),
     ]
 
 
@@ -155,7 +157,7 @@ def linear3(x3: torch.Tensor, w_tiles: torch.Tensor, M: int, N: int, K: int, *, 
             emit_b: Optional[torch.Tensor] = None, gamma_b: Optional[torch.Tensor] = None,
             ssq_out: Optional[torch.Tensor] = None, rope=None, row_pos=None, row_slot=None, k_cache=None, v_cache=None,
             n_q_heads: int = 0, n_kv_heads: int = 0, cache_len: int = 0, w_scale: Optional[torch.Tensor] = None,
-            v_x3: Optional[torch.Tensor] = None):
+            v_x3: Optional[torch.Tensor] = None, kv_format: int = 0):
     """The bf16-MFMA GEMM over an X3 operand; returns the fp32 ``out`` tensor (None for SWIGLU).
     ``w_scale`` given: ``w_tiles`` are e4m3 tiles (``pack_weight_fp8``)."""
     lib = E.load_library()
@@ -176,5 +178,6 @@ def linear3(x3: torch.Tensor, w_tiles: torch.Tensor, M: int, N: int, K: int, *, 
     a.n_q_heads, a.n_kv_heads, a.cache_len = n_q_heads, n_kv_heads, cache_len
     a.w_format, a.w_scale_dev = (1, E.dptr(w_scale)) if w_scale is not None else (0, None)
     a.v_x3_dev = E.dptr(v_x3)
+    a.kv_format = int(kv_format)
     E.check(lib.smoltts_k_gemm3(C.byref(a), E.current_stream_ptr()), "smoltts_k_gemm3")
     return out

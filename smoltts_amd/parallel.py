@@ -76,6 +76,26 @@ def all_reduce_sum(value: float, device) -> float:
     return float(t.item())
 
 
+def ranks_seen(device) -> int:
+    """How many ranks the collective backend really connects: an all-reduce (sum) of one 1 per rank -- over RCCL on the
+    rank's GPU, over gloo on the CPU.  1 without a process group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    t = torch.ones(1, dtype=torch.float32, device=_reduce_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(float(t.item())))
+
+
+def all_gather_floats(value: float, device) -> List[float]:
+    """Every rank's ``value``, in rank order (reporting only)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=_reduce_device(device))
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
+
+
 def barrier() -> None:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         if dist.get_backend() == "nccl":  # RCCL: name the rank's own GPU instead of letting the collective guess it

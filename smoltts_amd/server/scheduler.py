@@ -76,6 +76,7 @@ class BatchScheduler:
         self._active: Dict[int, _Request] = {}
         self._free: List[int] = list(range(max_batch))
         self._stop = threading.Event()
+        self._wake = threading.Event()          # set by submit(): the idle worker sleeps on it (no peeking into the queue)
         self._finished: List[_Request] = []     # complete blocking utterances waiting for a codec slot
         self._batch_codec = None                # codec session of the blocking requests: CODEC_BATCH slots, one utterance each
         self._codec_jobs: List[Optional[_CodecJob]] = [None] * self.CODEC_BATCH
@@ -104,6 +105,7 @@ class BatchScheduler:
             raise RuntimeError("scheduler is not running: shutting down")
         req = _Request(text, voice, stream, min(max_new_tokens or self.settings.max_new_tokens, self.settings.max_new_tokens))
         self._pending.put(req)
+        self._wake.set()
         if self._dead is not None:  # lost the race with a failing worker: answer it ourselves
             self._end(req, RuntimeError(f"scheduler is not running: {self._dead}"))
         return req
@@ -144,6 +146,7 @@ class BatchScheduler:
                    (self._active or self._held is not None or not self._pending.empty() or self._codec_backlog() or self._deliveries)):
                 time.sleep(0.01)
         self._stop.set()
+        self._wake.set()
         self._thread.join(timeout=30)
         for name in ("_batch_codec", "_stream_codec"):
             if getattr(self, name) is not None:
@@ -435,10 +438,8 @@ class BatchScheduler:
                         if self._deliveries or self._codec_backlog():
                             self._deliver(wait=not self._codec_backlog())  # keep the passes coming while there is codec work
                             continue
-                        try:
-                            self._pending.put(self._pending.get(timeout=0.05))  # idle: wait for work without spinning
-                        except queue.Empty:
-                            pass
+                        self._wake.wait(timeout=0.05)  # idle: sleep until submit() (or close) without touching the queue
+                        self._wake.clear()
                         continue
                     self._tick_and_snapshot()          # tick k and its snapshot are queued ...
                     self._decode_finished(force=False)

@@ -25,10 +25,13 @@ class GenerationBlock(BaseModel):
     default_fast_temp: Optional[float] = 0.0
     min_p: Optional[float] = 0.10
     max_new_tokens: int = Field(default=1024, ge=1)
+    # extension: "reference" = what lm/utils/samplers.py:22-28 computes (its threshold never removes a token, so the draw is
+    # categorical over logits / temp); "intended" = keep p >= min_p * p_max.  The drop-in default is the reference's behaviour.
+    min_p_mode: Literal["reference", "intended"] = "reference"
 
     def to_settings(self) -> _GenerationSettings:
         return _GenerationSettings(default_temp=self.default_temp, default_fast_temp=self.default_fast_temp, min_p=self.min_p,
-                                   max_new_tokens=self.max_new_tokens)
+                                   max_new_tokens=self.max_new_tokens, min_p_mode=self.min_p_mode)
 
 
 class ServerSettings(BaseModel):

@@ -20,9 +20,30 @@ sys.path.insert(0, str(ROOT))
 from smoltts_amd.codec.synthetic import synthetic_mimi_encoder_state, synthetic_mimi_state, synthetic_pcm  # noqa: E402
 
 
+def long_vector():
+    """A longer utterance (30 frames = 60 transformer positions, several SEANet halo refills in streaming decode)."""
+    from transformers import MimiConfig, MimiModel
+
+    seed, B, F = 5, 1, 30
+    st = synthetic_mimi_state(seed=seed)
+    m = MimiModel(MimiConfig()).eval()
+    res = m.load_state_dict(st, strict=False)
+    assert not res.unexpected_keys
+    codes = torch.randint(0, 2048, (B, 8, F), generator=torch.Generator().manual_seed(12))
+    with torch.no_grad():
+        pcm = m.decode(codes)[0]
+    fp = float(sum(float(v.double().abs().sum()) for v in st.values()))
+    np.savez_compressed(Path(__file__).resolve().parent / "mimi_hf_long.npz", seed=seed, codes=codes.numpy().astype(np.int32),
+                        pcm=pcm.numpy().astype(np.float32), fingerprint=fp)
+    print("wrote mimi_hf_long.npz", pcm.shape, float(pcm.pow(2).mean().sqrt()))
+
+
 def main():
     from transformers import MimiConfig, MimiModel
 
+    if "--only-long" in sys.argv:
+        return long_vector()
+    long_vector()
     seed, B, F = 3, 2, 6
     st = synthetic_mimi_state(seed=seed)
     m = MimiModel(MimiConfig()).eval()

@@ -1,0 +1,51 @@
+"""`python bench.py --gpus N` must start its own ranks (the driver runs exactly that command): the parent spawns N children
+before any GPU call, relays rank 0's JSON line and returns the children's exit code.  Rehearsed here on CPU over gloo
+(`--rehearse-launcher`: the bench's distributed plumbing without compute)."""
+import json
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _run(extra_env=None, *args, timeout=240):
+    env = dict(os.environ, TORCH_COMPILE_DISABLE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout)
+    return r, time.time() - t0
+
+
+def test_bench_self_launches_two_ranks_and_reports_ranks_seen():
+    r, _ = _run(None, "--gpus", "2", "--rehearse-launcher", "--steps", "2", "--warmup", "1", "--batch", "3")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2                 # the all-reduce of ones saw both ranks
+    assert d["utterances_sharded"] == 6 and d["arena_identical_on_all_ranks"] is True and d["arena_bytes"] > 0
+    assert d["value"] is None and "REHEARSAL" in d["metric"]         # never mistaken for a measurement
+
+
+def test_a_failing_rank_ends_the_run_with_its_exit_code():
+    """Rank 1 dies after the rendezvous; rank 0 is then stuck in a collective: the launcher must stop it and return
+    non-zero instead of hanging."""
+    r, took = _run({"SMOLTTS_BENCH_FAIL_RANK": "1"}, "--gpus", "2", "--rehearse-launcher", timeout=240)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert "rank 1 exited with 3" in r.stderr and took < 200
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+
+
+def test_under_an_external_launcher_the_process_is_a_rank():
+    """torch.distributed.run sets WORLD_SIZE: bench.py must then NOT spawn anything (here: WORLD_SIZE=1 -> plain rank 0)."""
+    r, _ = _run({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "1", "--rehearse-launcher")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1
+    r, _ = _run({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "2", "--rehearse-launcher")
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr          # mismatch is an error, not a silent 1-rank run

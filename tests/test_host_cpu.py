@@ -156,6 +156,24 @@ def test_library_exports_every_declared_symbol():
     assert isinstance(lib.smoltts_last_error(), bytes)
 
 
+def test_product_library_has_no_debug_state_and_fixed_flags():
+    """The event / cycle-stamp hooks exist only in -DSMOLTTS_DEBUG_HOOKS variants (separate directory); the product
+    library's objects carry the flag set they were built with, and extra flags are refused for the product path."""
+    import subprocess
+
+    from smoltts_amd import build, engine
+
+    build.build_library()
+    syms = subprocess.run(["nm", "-D", str(engine.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    for banned in ("smoltts_debug_set_stamps", "smoltts_profile_begin", "smoltts_profile_end", "smoltts_debug_duplicate"):
+        assert banned not in syms, f"{banned} is exported by the product library"
+    stamp = (build.CSRC / "build" / "flags.txt").read_text()
+    assert stamp.splitlines()[1] == " ".join(build.PRODUCT_FLAGS) and "-D" not in stamp
+    with pytest.raises(ValueError):
+        build.build_library(extra_flags=["-DSMOLTTS_DBG_PIECES=1"])      # variants only
+    assert build.variant_path("hooks").parent.parent.name == "variants" and build.variant_path("hooks") != engine.LIB_PATH
+
+
 def test_product_never_imports_the_oracle_and_fails_without_library(tmp_path):
     for p in (ROOT / "smoltts_amd").rglob("*.py"):
         src = p.read_text()
@@ -172,3 +190,20 @@ def test_product_never_imports_the_oracle_and_fails_without_library(tmp_path):
         cfg = named_config("tiny")
         with pytest.raises(engine.SmolttsError):  # no GPU => loud failure, never a CPU fallback
             engine.LMEngine(cfg, synthetic_lm_state(cfg), TokenConfig(270, 266, 320, 2367))
+
+
+def test_min_p_mode_defaults_to_the_references_behaviour():
+    """lm/utils/samplers.py:22-28 never removes a token (its threshold is built from the token's own log-probability):
+    the drop-in default must sample plain categorical; the intended rule is selectable."""
+    from smoltts_amd.config import GenerationSettings
+    from smoltts_amd.server.settings import GenerationBlock, ServerSettings
+
+    assert GenerationSettings(min_p=0.1).effective_min_p == 0.0
+    assert GenerationSettings(min_p=0.1, min_p_mode="intended").effective_min_p == pytest.approx(0.1)
+    assert GenerationSettings(min_p=None, min_p_mode="intended").effective_min_p == 0.0
+    with pytest.raises(ValueError):
+        GenerationSettings(min_p_mode="sometimes")
+    blk = GenerationBlock()
+    assert blk.min_p == pytest.approx(0.1) and blk.min_p_mode == "reference" and blk.to_settings().effective_min_p == 0.0
+    st = ServerSettings(checkpoint_dir="x", generation={"min_p": 0.2, "min_p_mode": "intended"})
+    assert st.generation.to_settings().effective_min_p == pytest.approx(0.2)

@@ -1,0 +1,287 @@
+"""Round-2 parity cases: BASELINE config 5 at its stated shape, the bf16 KV-cache option, the per-session measurement aid,
+the position record of the smallest top-2 gap, and the third-party Mimi vectors decoded directly on the HIP engine."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench_prompts(pe, n, seed=2):
+    from smoltts_amd.prompt import VOICES
+
+    rng = np.random.default_rng(seed)
+    out = []
+    for u in range(n):  # the bench's prompt recipe
+        k = int(rng.integers(40, 161))
+        out.append(pe.build_prompt("".join(chr(int(c)) for c in rng.integers(32, 127, size=k)), VOICES[u % len(VOICES)]))
+    return out
+
+
+def _teacher_forced_flips(orc, prompts, codes, F):
+    """Every id the engine emitted must be the oracle's argmax given the engine's own history; returns
+    (ids checked, ids that differ, largest relative logit gap at a difference)."""
+    flips, checked, worst = 0, 0, 0.0
+    for b, prompt in enumerate(prompts):
+        grid = codes[b, :F].T
+        full = torch.cat([torch.from_numpy(prompt).long(), torch.from_numpy(grid.astype(np.int64))], dim=1)
+        tl, cl = orc.teacher_forced(full)
+        T = prompt.shape[1]
+        for f in range(F):
+            s = T - 1 + f
+            for i, lg in enumerate([tl[s]] + [cl[s, k] for k in range(cl.shape[1])]):
+                checked += 1
+                want, got = int(lg.argmax()), int(grid[i, f])
+                if want != got:
+                    flips += 1
+                    worst = max(worst, float(lg[want] - lg[got]) / float(lg.abs().max()))
+    return checked, flips, worst
+
+
+def test_config5_150m_fp8_chunked_prefill_b64():
+    """BASELINE.json configs[4] as written: smoltts_byte_150m, fp8 (e4m3 storage) weights, prompts prefilled in chunks of 128
+    columns, B = 64 utterances, 24 frames -- all 64 x 24 x 9 ids checked teacher-forced against the oracle on the dequantised model."""
+    from oracle.lm_oracle import LMOracle, OracleLMConfig
+    from smoltts_amd.config import NumericsMode, TokenConfig
+    from smoltts_amd.engine import LMEngine, LMSession
+    from smoltts_amd.packing import fp8_reference_state
+    from smoltts_amd.prompt import PromptEncoder
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+    from smoltts_amd.tokenizer import load_tokenizer
+
+    torch.set_num_threads(16)
+    cfg = named_config("smoltts_byte_150m")
+    state = synthetic_lm_state(cfg, seed=0)
+    tok = load_tokenizer()
+    tc = TokenConfig.from_tokenizer(tok, cfg)
+    eng = LMEngine(cfg, state, tc, NumericsMode.torch_reference(), weight_format="fp8")
+    assert eng.weight_format == "fp8"
+    pe = PromptEncoder(tok, tc.semantic_start_id, cfg.num_codebooks, cfg.duplicate_code_0)
+    B, F, chunk = 64, 24, 128
+    prompts = _bench_prompts(pe, B)
+    assert max(p.shape[1] for p in prompts) > chunk > min(p.shape[1] for p in prompts)  # some prompts take two calls, some one
+    sess = LMSession(eng, B, max_seq=max(p.shape[1] for p in prompts) + F + 2, max_rows=sum(min(p.shape[1], chunk) for p in prompts), max_frames=F)
+    calls = []
+    sess.prefill_chunked(prompts, stop_on_eos=False, chunk=chunk, between=lambda: calls.append(1))
+    assert len(calls) == 1
+    sess.decode(F - 1)
+    codes, n, done, margin = sess.fetch()
+    sess.close()
+    assert (n == F).all()
+    rcfg, rstate = fp8_reference_state(cfg, state)
+    orc = LMOracle(OracleLMConfig.from_dict(rcfg.__dict__), rstate)
+    checked, flips, worst = _teacher_forced_flips(orc, prompts, codes, F)
+    print(f"config 5 (150m fp8, chunk 128, B=64): {checked} ids checked, {flips} differ from the oracle's teacher-forced argmax "
+          f"(largest relative gap {worst:.2e}); engine min top-2 margin {margin.min():.2e}")
+    assert checked == B * F * 9 and worst < 3e-5 and flips <= 8
+    eng.close()
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(12, 4), (9, 3)])
+def test_attention_over_a_bf16_cache(Hq, Hkv):
+    """Decode and prefill attention kernels over bf16 K/V == fp32 attention over the same (rounded) values."""
+    from smoltts_amd import ops
+
+    g = torch.Generator().manual_seed(Hq)
+    slots, cache_len = 4, 300
+    kc = torch.randn(slots, Hkv, cache_len, 64, generator=g).bfloat16()
+    vc = torch.randn(slots, Hkv, cache_len, 64, generator=g).bfloat16()
+    for rows in (9, 400):  # 9 rows: one workgroup per (row, kv head); 400 x Hkv >= 1024: the MFMA prefill kernel
+        q = torch.randn(rows, Hq * 64, generator=g)
+        row_pos = torch.randint(0, cache_len, (rows,), generator=g, dtype=torch.int32)
+        row_pos[:4] = torch.tensor([0, 1, 17, 299], dtype=torch.int32)
+        row_slot = torch.randint(0, slots, (rows,), generator=g, dtype=torch.int32)
+        out = ops.attention(q.cuda(), kc.cuda(), vc.cuda(), row_pos.cuda(), row_slot.cuda(), Hq).cpu()
+        ref32 = ops.attention(q.cuda(), kc.float().cuda(), vc.float().cuda(), row_pos.cuda(), row_slot.cuda(), Hq).cpu()
+        G = Hq // Hkv
+        for r in list(range(6)) + [rows - 1]:
+            p, s = int(row_pos[r]), int(row_slot[r])
+            K = kc[s, :, : p + 1].float().repeat_interleave(G, dim=0)
+            V = vc[s, :, : p + 1].float().repeat_interleave(G, dim=0)
+            a = torch.softmax(q[r].view(Hq, 1, 64) @ K.transpose(1, 2) / 8.0, dim=-1) @ V
+            assert float((out[r] - a.reshape(-1)).abs().max() / a.abs().max()) < 2e-5, (rows, r, p)
+        assert torch.equal(out, ref32)  # same kernels, same arithmetic: only the storage of K/V differs
+
+
+@pytest.mark.parametrize("cfgname,B,F", [("tiny", 4, 16), ("smoltts_byte_70m", 3, 10)])
+def test_bf16_kv_session_matches_the_oracle_with_rounded_kv(cfgname, B, F):
+    from oracle.lm_oracle import LMOracle, OracleLMConfig
+    from smoltts_amd.config import TokenConfig
+    from smoltts_amd.engine import LMEngine, LMSession
+    from smoltts_amd.prompt import PromptEncoder
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+    from smoltts_amd.tokenizer import load_tokenizer
+
+    cfg = named_config(cfgname)
+    state = synthetic_lm_state(cfg, seed=13)
+    tok = load_tokenizer()
+    tc = TokenConfig.from_tokenizer(tok, cfg)
+    eng = LMEngine(cfg, state, tc)
+    pe = PromptEncoder(tok, tc.semantic_start_id, cfg.num_codebooks, cfg.duplicate_code_0)
+    prompts = _bench_prompts(pe, B, seed=4)
+    out = {}
+    for kv in ("fp32", "bf16"):
+        s = LMSession(eng, B, max_seq=max(p.shape[1] for p in prompts) + F + 2, max_rows=1024, max_frames=F, kv_dtype=kv)
+        s.prefill_chunked(prompts, stop_on_eos=False, chunk=64)  # later chunks attend to cached (rounded) K/V of earlier ones
+        s.decode(F - 1)
+        out[kv] = s.fetch()[0][:, :F].copy()
+        s.close()
+    orc = LMOracle(OracleLMConfig.from_dict(cfg.__dict__), state, kv_bf16=True)
+    logs = orc.generate([torch.from_numpy(p) for p in prompts], max_frames=F, stop_on_eos=False)
+    same = sum(int(np.array_equal(out["bf16"][b].T, logs[b].as_tensor().numpy())) for b in range(B))
+    checked, flips, worst = _teacher_forced_flips(orc, prompts, out["bf16"], F)
+    print(f"{cfgname} bf16 KV: {same}/{B} utterances bit-identical to the rounded-KV oracle; teacher-forced {flips}/{checked} differ (gap {worst:.2e})")
+    assert worst < 3e-5 and flips <= 2 and same >= B - 1
+    # and the rounding is really in effect: the fp32-KV oracle, teacher-forced on these ids, sees logits that differ
+    exact = LMOracle(OracleLMConfig.from_dict(cfg.__dict__), state)
+    full = torch.cat([torch.from_numpy(prompts[0]).long(), torch.from_numpy(out["bf16"][0].T.astype(np.int64))], dim=1)
+    assert not torch.equal(exact.teacher_forced(full)[0], orc.teacher_forced(full)[0])
+    eng.close()
+
+
+def test_150m_b32_bf16_kv_teacher_forced_parity_and_long_context_time():
+    """The headline shape with the bf16 KV cache: 32 x 48 x 9 ids teacher-forced against the rounded-KV oracle; prints the
+    frame time at a long context for both cache formats."""
+    from oracle.lm_oracle import LMOracle, OracleLMConfig
+    from smoltts_amd.config import TokenConfig
+    from smoltts_amd.engine import LMEngine, LMSession
+    from smoltts_amd.prompt import PromptEncoder
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+    from smoltts_amd.tokenizer import load_tokenizer
+
+    torch.set_num_threads(16)
+    cfg = named_config("smoltts_byte_150m")
+    state = synthetic_lm_state(cfg, seed=0)
+    tok = load_tokenizer()
+    tc = TokenConfig.from_tokenizer(tok, cfg)
+    eng = LMEngine(cfg, state, tc)
+    pe = PromptEncoder(tok, tc.semantic_start_id, cfg.num_codebooks, cfg.duplicate_code_0)
+    prompts = _bench_prompts(pe, 32)
+    F = 48
+    sess = LMSession(eng, 32, max_seq=max(p.shape[1] for p in prompts) + F + 2, max_rows=sum(p.shape[1] for p in prompts), max_frames=F, kv_dtype="bf16")
+    sess.prefill(prompts, stop_on_eos=False)
+    sess.decode(F - 1)
+    codes, n, _, margin = sess.fetch()
+    sess.close()
+    orc = LMOracle(OracleLMConfig.from_dict(cfg.__dict__), state, kv_bf16=True)
+    checked, flips, worst = _teacher_forced_flips(orc, prompts, codes, F)
+    print(f"150m B=32 bf16 KV: {checked} ids checked, {flips} differ (largest relative gap {worst:.2e}); min margin {margin.min():.2e}")
+    assert (n == F).all() and worst < 3e-5 and flips <= 8
+    times = {}
+    for kv in ("fp32", "bf16"):
+        s = LMSession(eng, 32, max_seq=2040, max_rows=sum(p.shape[1] for p in prompts), max_frames=1900, kv_dtype=kv)
+        s.prefill(prompts, stop_on_eos=False)
+        s.decode(1700)  # context ~1800
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); s.decode(32); b.record()
+        torch.cuda.synchronize()
+        times[kv] = a.elapsed_time(b) / 32
+        s.close()
+    print(f"150m B=32 frame graph at ~1800 tokens of context: fp32 KV {times['fp32']:.3f} ms, bf16 KV {times['bf16']:.3f} ms")
+    eng.close()
+
+
+def test_measure_duplicate_is_per_session_and_changes_no_ids():
+    """The in-situ timing aid doubles launches of ONE session; another session of the same engine is untouched, and the
+    doubled launches are idempotent (ids and margins identical)."""
+    from smoltts_amd.config import TokenConfig
+    from smoltts_amd.engine import EPI_QKV_ROPE, EPI_STORE, EPI_SWIGLU, LMEngine, LMSession, SmolttsError
+    from smoltts_amd.prompt import PromptEncoder
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+    from smoltts_amd.tokenizer import load_tokenizer
+
+    cfg = named_config("tiny")
+    tok = load_tokenizer()
+    tc = TokenConfig.from_tokenizer(tok, cfg)
+    eng = LMEngine(cfg, synthetic_lm_state(cfg, seed=4), tc)
+    pe = PromptEncoder(tok, tc.semantic_start_id, cfg.num_codebooks, cfg.duplicate_code_0)
+    prompts = [pe.build_prompt("measure twice", "heart"), pe.build_prompt("cut once", "sky")]
+
+    def run(code=None, n=0):
+        s = LMSession(eng, 2, max_seq=128, max_rows=128, max_frames=12)
+        if code is not None:
+            s.measure_duplicate(code, n)
+        s.prefill(prompts, stop_on_eos=False)
+        s.decode(11)
+        out = s.fetch()
+        at = s.margin_at.cpu().numpy().copy()
+        s.close()
+        return out[0].copy(), out[3].copy(), at
+
+    base = run()
+    for code, n in ((EPI_SWIGLU, 0), (EPI_QKV_ROPE, 0), (EPI_STORE, cfg.codebook_size), (100, 0), (101, 0)):
+        got = run(code, n)
+        assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]) and np.array_equal(got[2], base[2]), code
+    s = LMSession(eng, 2, max_seq=64, max_rows=64, max_frames=4)
+    with pytest.raises(SmolttsError):
+        s.measure_duplicate(1, 0)  # EPI_RESID accumulates into its input: refused
+    s.close()
+    # where the smallest gap occurred: frame * 64 + step, inside the run
+    codes, margin, at = base
+    assert ((at // 64) < 12).all() and ((at % 64) <= cfg.max_fast_seqlen).all() and np.isfinite(margin).all()
+    eng.close()
+
+
+def test_margin_position_matches_the_oracle():
+    from oracle.lm_oracle import LMOracle, OracleLMConfig
+    from smoltts_amd.config import TokenConfig
+    from smoltts_amd.engine import LMEngine, LMSession
+    from smoltts_amd.prompt import PromptEncoder
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+    from smoltts_amd.tokenizer import load_tokenizer
+
+    cfg = named_config("tiny")
+    state = synthetic_lm_state(cfg, seed=6)
+    tok = load_tokenizer()
+    tc = TokenConfig.from_tokenizer(tok, cfg)
+    eng = LMEngine(cfg, state, tc)
+    pe = PromptEncoder(tok, tc.semantic_start_id, cfg.num_codebooks, cfg.duplicate_code_0)
+    prompt = pe.build_prompt("where is the narrowest decision?", "nova")
+    F = 20
+    s = LMSession(eng, 1, max_seq=128, max_rows=128, max_frames=F)
+    s.prefill([prompt], stop_on_eos=False)
+    s.decode(F - 1)
+    codes, n, _, margin = s.fetch()
+    at = int(s.margin_at.cpu()[0])
+    s.close()
+    orc = LMOracle(OracleLMConfig.from_dict(cfg.__dict__), state)
+    full = torch.cat([torch.from_numpy(prompt).long(), torch.from_numpy(codes[0, :F].T.astype(np.int64))], dim=1)
+    tl, cl = orc.teacher_forced(full)
+    T = prompt.shape[1]
+    gaps = np.zeros((F, 1 + cfg.max_fast_seqlen))
+    for f in range(F):
+        for i, lg in enumerate([tl[T - 1 + f]] + [cl[T - 1 + f, k] for k in range(cl.shape[1])]):
+            top = torch.topk(lg, 2).values
+            gaps[f, i] = float(top[0] - top[1])
+    f_min, i_min = np.unravel_index(np.argmin(gaps), gaps.shape)
+    assert (at // 64, at % 64) == (int(f_min), int(i_min)), (at, f_min, i_min)
+    assert margin[0] == pytest.approx(gaps[f_min, i_min], rel=0.05, abs=2e-6)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["mimi_hf.npz", "mimi_hf_long.npz"])
+def test_mimi_hf_vectors_decoded_on_the_hip_engine(golden_dir, name):
+    """Third-party pin without the oracle hop: the codes of tests/golden/mimi_hf.npz decoded by the HIP engine against the PCM
+    that transformers.MimiModel.decode produced for them (tests/golden/make_mimi_goldens.py), batch and streaming."""
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+    from smoltts_amd.engine import MimiEngine, MimiSession
+
+    g = np.load(golden_dir / name)
+    codes = torch.from_numpy(g["codes"].astype(np.int32))  # (B, 8, F)
+    want = g["pcm"]
+    want = want.reshape(want.shape[0], -1)
+    mst = synthetic_mimi_state(seed=int(g["seed"]))
+    B, Q, F = codes.shape
+    eng = MimiEngine(mst, num_codebooks=Q, window=int(g["window"]) if "window" in g.files else 250, max_positions=2 * F + 16)
+    dev = codes.permute(0, 2, 1).contiguous().cuda()  # [B, F, 8]
+    fp = float(sum(float(v.double().abs().sum()) for v in mst.values()))
+    assert abs(fp - float(g["fingerprint"])) <= 1e-9 * fp, "synthetic Mimi weight stream drifted from the golden one"
+    for chunk in (F, 1, 4):
+        sess = MimiSession(eng, max_batch=B, max_chunk_frames=chunk)
+        pcm = sess.decode(dev, code_offset=0).cpu().numpy()
+        sess.close()
+        rms = float(np.sqrt(np.mean((pcm - want) ** 2)))
+        print(f"{name} on the HIP engine, chunks of {chunk}: rms err {rms:.2e} (signal rms {float(np.sqrt(np.mean(want ** 2))):.2e})")
+        assert pcm.shape == want.shape and rms <= 1e-4
+    eng.close()

@@ -29,17 +29,27 @@ def _chi2_ok(counts, probs, n):
     return chi2 < dof + 6 * math.sqrt(2 * dof), chi2, dof  # ~6 sigma
 
 
-@pytest.mark.parametrize("temp,min_p", [(1.0, 0.0), (0.7, 0.0), (0.5, 0.1)])
-def test_sampler_follows_softmax(temp, min_p):
+@pytest.mark.parametrize("temp,min_p,mode", [(1.0, None, "reference"), (0.7, None, "intended"), (0.5, 0.1, "intended"), (0.5, 0.1, "reference")])
+def test_sampler_follows_softmax(temp, min_p, mode):
+    """Both readings of ``min_p``: "reference" = what lm/utils/samplers.py:22-28 computes (the threshold is the token's own
+    log-probability + log(min_p), so nothing is removed: categorical over logits / temp, the drop-in default); "intended" =
+    keep p >= min_p * p_max.  The device gets ``GenerationSettings.effective_min_p``."""
+    from smoltts_amd.config import GenerationSettings
+
     g = torch.Generator().manual_seed(3)
     V = 2368
     row = torch.randn(V, generator=g) * 2.0
     n = 60000
-    ids = _sample(row, n, temp, min_p, seed=12345)
+    eff = GenerationSettings(default_temp=temp, min_p=min_p, min_p_mode=mode).effective_min_p
+    assert eff == (min_p if (mode == "intended" and min_p) else 0.0)
+    ids = _sample(row, n, temp, eff, seed=12345)
     z = (row - row.max()) / temp
-    if min_p > 0:
-        z = torch.where(z >= math.log(min_p), z, torch.full_like(z, float("-inf")))
+    if eff > 0:
+        z = torch.where(z >= math.log(eff), z, torch.full_like(z, float("-inf")))
         assert set(np.unique(ids)).issubset(set(torch.nonzero(torch.isfinite(z)).flatten().tolist()))
+    elif min_p:  # reference mode with the server's min_p = 0.1: tokens below the "intended" cut must still be drawn
+        below = (z < math.log(min_p)).numpy()
+        assert below[ids].sum() > 0.5 * n * float(torch.softmax(z.double(), 0)[torch.from_numpy(below)].sum())
     probs = torch.softmax(z.double(), dim=0).numpy()
     counts = np.bincount(ids, minlength=V).astype(np.float64)
     ok, chi2, dof = _chi2_ok(counts, probs, n)

@@ -53,8 +53,7 @@ cases = [("wqkv GEMM + RoPE + cache (N=1280)", 5, (cfg.n_head + 2 * cfg.n_local_
          ("depth attention (<= 8 keys)", 100, 0, F * (S - 1)),
          ("slow attention (context ~300)", 101, 0, L)]
 for name, epi, n, count in cases:
-    check(lib.smoltts_debug_duplicate(epi, n), "dup")
-    check(lib.smoltts_session_drop_graph(sess.handle), "drop")
+    sess.measure_duplicate(epi, n)  # this session only; drops its captured graphs
     t = timed()
     print(f"{name:40s}: {count:3d} extra launches, frame {t:7.1f} us -> {(t - base) / count:5.2f} us per launch")
-check(lib.smoltts_debug_duplicate(-1, 0), "dup")
+sess.measure_duplicate(-1)

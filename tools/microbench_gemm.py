@@ -83,6 +83,8 @@ def stamps():
     """Cycle stamps of workgroup (0,0) of one w13 launch: where a workgroup's latency goes."""
     import ctypes
 
+    if not hasattr(E.load_library(), "smoltts_debug_set_stamps"):
+        raise SystemExit("cycle stamps need the hooks variant: SMOLTTS_LIB=$(python -m smoltts_amd.build --variant hooks | tail -1) python tools/microbench_gemm.py ...")
     lib = E.load_library()
     buf = torch.zeros(16 * 8 * 2, dtype=torch.int64, device="cuda")
     M, N, K = 32, 6144, 768

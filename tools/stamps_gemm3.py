@@ -4,8 +4,13 @@ import sys
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import os  # noqa: E402
+
 import torch  # noqa: E402
 
+from smoltts_amd.build import build_library  # noqa: E402
+
+os.environ["SMOLTTS_LIB"] = str(build_library(variant="hooks"))  # the cycle stamps exist only in the -DSMOLTTS_DEBUG_HOOKS variant
 from smoltts_amd import engine as E, ops  # noqa: E402
 
 lib = E.load_library()
