@@ -66,6 +66,11 @@ struct SmolttsSession {
   hipGraphExec_t tail_exec;    // the tail alone (slow head + depth steps + commit) as run after a prefill
   bool tail_ready;
   bool prefilled;
+  // bounded run-ahead of the host over the GPU (smoltts_lm_decode): an event every `flight_group` frame graphs, the host
+  // waits for the one recorded two groups ago before it launches further
+  hipEvent_t flight_ev[2];
+  bool flight_live[2];
+  int flight_cur, flight_count, flight_group;
   // measurement aid of THIS session (smoltts_session_measure_duplicate): launches of one kernel class are issued twice
   int dup_code, dup_n;
 };
@@ -599,6 +604,13 @@ int smoltts_session_create_kv(SmolttsEngine* e, void* slab_dev, size_t slab_byte
       return SMOLTTS_E_HIP;
     }
   }
+  {  // frames the host may run ahead of the GPU: SMOLTTS_MAX_FRAMES_IN_FLIGHT (default 16; 0 = unbounded)
+    const char* lim = getenv("SMOLTTS_MAX_FRAMES_IN_FLIGHT");
+    const int limit = lim ? atoi(lim) : 16;
+    s->flight_group = limit > 0 ? (limit + 1) / 2 : 0;
+    for (int k = 0; k < 2; ++k)
+      if (hipEventCreateWithFlags(&s->flight_ev[k], hipEventDisableTiming) != hipSuccess) s->flight_group = 0;
+  }
   hipLaunchKernelGGL(init_state_kernel, dim3((max_batch + 63) / 64), dim3(64), 0, 0, max_batch, e->cfg.n_fast, s->iota,
                      s->fastpos, s->pos, s->frames, s->done, s->mask, s->margin, s->margin_at, s->cur_col, s->new_col, s->salt);
   hipError_t err = hipGetLastError();
@@ -620,6 +632,8 @@ void smoltts_session_destroy(SmolttsSession* s) {
   for (int k = 0; k < STAGE_RING; ++k)
     if (s->stage_ev[k]) (void)hipEventDestroy(s->stage_ev[k]);
   if (s->h_stage) (void)hipHostFree(s->h_stage);
+  for (int k = 0; k < 2; ++k)
+    if (s->flight_ev[k]) (void)hipEventDestroy(s->flight_ev[k]);
   delete s;
 }
 
@@ -725,7 +739,25 @@ int smoltts_lm_decode(SmolttsSession* s, int32_t n_frames, void* stream) {
     ST_TRY(capture_graph(st, &s->graph_exec, [&](hipStream_t cap) { return run_decode_frame(s, cap); }));
     s->graph_ready = true;
   }
-  for (int f = 0; f < n_frames; ++f) ST_CHECK_HIP(hipGraphLaunch(s->graph_exec, st));
+  // Bounded run-ahead: a frame is ~230 AQL packets, and nothing stops a caller from queueing hundreds of frames.  The
+  // hardware queue holds 16K packets; the runtime copes with a full ring, but a profiler that rewrites every dispatch into
+  // several packets (rocprofv3 --pmc: counter start / stop + serialisation barriers around each kernel) overflows its
+  // intercept queue and the run hangs behind the queued graph launches (round 1: gpurun_out/probe_d.log stops at the
+  // first un-synchronised run of 63 frame graphs, while 3 frames per synchronisation completed).  So the host never
+  // runs more than SMOLTTS_MAX_FRAMES_IN_FLIGHT frames ahead: it records an event every half limit and, before queueing
+  // more, waits for the event of two groups ago -- the GPU queue never drains, the host merely stops piling up packets.
+  for (int f = 0; f < n_frames; ++f) {
+    if (s->flight_group > 0 && s->flight_count >= s->flight_group) {
+      const int k = s->flight_cur;
+      ST_CHECK_HIP(hipEventRecord(s->flight_ev[k], st));
+      s->flight_live[k] = true;
+      if (s->flight_live[k ^ 1]) ST_CHECK_HIP(hipEventSynchronize(s->flight_ev[k ^ 1]));
+      s->flight_cur = k ^ 1;
+      s->flight_count = 0;
+    }
+    ST_CHECK_HIP(hipGraphLaunch(s->graph_exec, st));
+    s->flight_count++;
+  }
   return SMOLTTS_OK;
 }
 

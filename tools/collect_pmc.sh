@@ -1,12 +1,17 @@
 #!/bin/bash
 # HBM traffic of the hot kernels, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in separate
 # rocprofv3 --pmc passes (they do not fit one pass), kernel trace only, the program itself after `--`.
-# Run on the GPU box from the repo root:  bash tools/collect_pmc.sh   -> gpurun_out/pmc_{fetch,write}/, pmc_summary.*
+# The program is the bench command itself (no CPU sample, no latency probe, fewer steps: counters serialise every kernel).
+# SMOLTTS_MAX_FRAMES_IN_FLIGHT=2: with --pmc every dispatch becomes several packets and the profiler's intercept queue
+# does not survive thousands of queued dispatches (round 1 hang) -- the library's bounded run-ahead keeps the host at most
+# 2 frames (~460 dispatches) ahead of the GPU; nothing else about the run changes.
+# Run on the GPU box from the repo root:  bash tools/collect_pmc.sh [tag]   -> gpurun_out/pmc_{fetch,write}/, pmc_summary.*
 set -e
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-# only the decode-loop kernels are instrumented (rocprofv3's counter service crashed on the prefill launches)
-FILTER='gemm3_kernel|attn_kernel|attn_short_kernel|argmax_kernel'
-ARGS="tools/pmc_decode.py"
-timeout -k 10 150 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$FILTER" --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o pmc -- python3 $ARGS > gpurun_out/pmc_fetch.log 2>&1 < /dev/null
-timeout -k 10 150 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$FILTER" --kernel-trace --output-format csv -d gpurun_out/pmc_write -o pmc -- python3 $ARGS > gpurun_out/pmc_write.log 2>&1 < /dev/null
-python3 tools/summarize_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_summary
+export SMOLTTS_MAX_FRAMES_IN_FLIGHT=2
+ARGS="bench.py --cpu-frames 0 --no-latency --steps 2 --warmup 1"
+rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
+timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o pmc -- python3 $ARGS > gpurun_out/pmc_fetch.log 2>&1 < /dev/null
+timeout -k 10 280 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o pmc -- python3 $ARGS > gpurun_out/pmc_write.log 2>&1 < /dev/null
+python3 tools/summarize_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_summary "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of \`python3 $ARGS\` with SMOLTTS_MAX_FRAMES_IN_FLIGHT=2; read = 2 x FETCH_SIZE (gfx950)"

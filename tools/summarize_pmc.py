@@ -37,6 +37,7 @@ for _, (name, grid, wg), n, f_kb, w_kb in rows:
     if name.startswith("gemm3_kernel<1, 3, 3, 2") and grid == 128 * 2 * 512:
         json.dump({"kernel": name + " (w1|w3 GEMM + SwiGLU, 150m, B=32)", "dispatches": n, "FETCH_SIZE_avg_KB": f_kb, "WRITE_SIZE_avg_KB": w_kb,
                    "hbm_bytes_per_launch": int((2 * f_kb + w_kb) * 1024),
-                   "correction": "read = 2 x FETCH_SIZE x 1024 (gfx950), write = WRITE_SIZE x 1024"}, open(sys.argv[3] + "_w13.json", "w"), indent=1)
+                   "correction": "read = 2 x FETCH_SIZE x 1024 (gfx950), write = WRITE_SIZE x 1024",
+                   "source": sys.argv[4] if len(sys.argv) > 4 else "tools/collect_pmc.sh"}, open(sys.argv[3] + "_w13.json", "w"), indent=1)
         break
 print(open(sys.argv[3] + ".txt").read()[:3000])
