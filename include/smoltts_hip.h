@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SMOLTTS_ABI_VERSION 1
+#define SMOLTTS_ABI_VERSION 2
 
 enum {
   SMOLTTS_OK = 0,
@@ -52,6 +52,10 @@ int smoltts_abi_version(void);
  * N is padded to a multiple of 16 with zero rows; K must be a multiple of 32.
  * smoltts_amd/packing.py produces it.
  * ------------------------------------------------------------------------------------------- */
+
+/* "W3" tiles (Mimi many-row GEMMs, smoltts_amd/csrc/gemm_b3.hip): an fp32 [N][K] matrix as three bf16 pieces hi + mid + lo
+ * (== the fp32 value exactly); tile (nt, kc) is 3 KiB at (nt * K/32 + kc) * 3072: piece p at + p * 1024 in the bf16 T16x32
+ * lane order above.  smoltts_amd/packing.py (tile_w3) produces it. */
 
 /* Byte offsets into the LM weight arena. */
 typedef struct SmolttsBlockWeights {
@@ -201,12 +205,14 @@ typedef struct SmolttsMimiLayerWeights {
   uint64_t fc1;              /* fp32 T16x32 [2048][512] */
   uint64_t fc2;              /* fp32 T16x32 [512][2048] */
   uint64_t ls2;
+  uint64_t wqkv3, wo3, fc13, fc23;  /* the same four matrices as "W3" tiles (below); 0 = absent (fp32 kernels only) */
 } SmolttsMimiLayerWeights;
 
 typedef struct SmolttsMimiConv {
   uint64_t w;                /* fp32 T16x32 [N][K] GEMM form, see DESIGN.md "convolutions as GEMMs" */
   uint64_t b;                /* fp32 [N] (bias repeated per phase for transposed convs) */
   int32_t cin, cout, k, stride, transposed;
+  uint64_t w3;               /* the same GEMM matrix as "W3" tiles; 0 = absent */
 } SmolttsMimiConv;
 
 typedef struct SmolttsMimiConfig {
@@ -341,6 +347,8 @@ typedef struct SmolttsGemmArgs {
   float* k_cache_dev;         /* [slots][n_kv][cache_len][64] */
   float* v_cache_dev;
   int32_t n_q_heads, n_kv_heads, cache_len;
+  const void* w3_dev;         /* optional, fp32 weights only: the same matrix as "W3" tiles; many-row calls (M >= 256, N >= 64,
+                                 no prologue) then run on the bf16 matrix cores with split operands (fp32-grade results) */
 } SmolttsGemmArgs;
 
 int smoltts_k_gemm(const SmolttsGemmArgs* a, void* stream);

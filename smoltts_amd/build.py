@@ -23,7 +23,7 @@ from typing import Optional, Sequence
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libsmoltts_hip.so"
-SOURCES = ["api.hip", "gemm.hip", "gemm3.hip", "attention.hip", "small_ops.hip", "lm_engine.hip", "mimi_engine.hip", "mimi_encoder.hip",
+SOURCES = ["api.hip", "gemm.hip", "gemm_b3.hip", "gemm3.hip", "attention.hip", "small_ops.hip", "lm_engine.hip", "mimi_engine.hip", "mimi_encoder.hip",
            "seanet.hip"]
 ARCH = "gfx950"
 PRODUCT_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]

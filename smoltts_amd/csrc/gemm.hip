@@ -19,35 +19,9 @@
 //    bias, residual, SwiGLU, GELU, layer scale and RoPE + q/KV-cache scatter into the same launch.
 #include <stdlib.h>
 
-#include "common.h"
+#include "gemm_dev.h"
 
 namespace smoltts {
-
-struct GemmDev {
-  const char* w;
-  const float* x;
-  long ldx, x_bstride;
-  int rows_per_batch;
-  int M, N, K;
-  const float* gamma;
-  float eps;
-  const float* bias;
-  const float* scale;
-  const float* resid;
-  float* out;
-  long ldo, o_bstride;
-  float* raw_out;  // optional copy of the un-activated result (same row stride, own batch stride)
-  long raw_bstride;
-  int elu_out;     // apply ELU to what goes to `out`
-  long ldr, r_bstride;
-  const float* rope;
-  const int* row_pos;
-  const int* row_slot;
-  float* kc;
-  float* vc;
-  int n_q_heads, n_kv_heads, cache_len;
-  unsigned long long* stamps;  // diagnostic build aid (SMOLTTS debug API); nullptr in production
-};
 
 // cycle stamps of workgroup (0,0): [wave][slot] = {s_memtime, s_memrealtime}
 #ifdef SMOLTTS_DEBUG_HOOKS
@@ -61,16 +35,6 @@ struct GemmDev {
 #else
 #define STAMP(k) do { } while (0)
 #endif
-
-__device__ __forceinline__ long row_off(int m, int rpb, long ld, long bstride) {
-  if (rpb <= 0) return (long)m * ld;
-  int b = m / rpb;
-  return (long)b * bstride + (long)(m - b * rpb) * ld;
-}
-
-__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
-__device__ __forceinline__ float silu1(float x) { return x / (1.f + expf(-x)); }
-__device__ __forceinline__ float gelu1(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
 template <bool WF32, int MT, int U, int PRO, int EPI>
 __global__ __launch_bounds__(MT >= 4 ? 512 : 1024) void gemm_kernel(GemmDev p) {
@@ -388,54 +352,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmDev p, int WN) {
       const int n0 = (tile0 + t) * 16 + q * 4;
       if (n0 >= p.N) continue;
       float v[4] = {acc[t][mt][0], acc[t][mt][1], acc[t][mt][2], acc[t][mt][3]};
-      if (p.bias) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (n0 + i < p.N) v[i] += p.bias[n0 + i];
-      }
-      if (n0 + 4 > p.N) {  // N < 4: scalar tail (the 1-channel output conv)
-        for (int i = 0; i < 4 && n0 + i < p.N; ++i) p.out[orow + n0 + i] = p.elu_out ? elu1(v[i]) : v[i];
-        continue;
-      }
-      if (EPI == SMOLTTS_EPI_GELU) {
-        *reinterpret_cast<float4*>(p.out + orow + n0) = make_float4(gelu1(v[0]), gelu1(v[1]), gelu1(v[2]), gelu1(v[3]));
-        continue;
-      }
-      if (EPI == SMOLTTS_EPI_SCALE_RESID) {
-        const float4 rr = *reinterpret_cast<const float4*>(p.resid + row_off(m, p.rows_per_batch, p.ldr, p.r_bstride) + n0);
-        const float4 sc = *reinterpret_cast<const float4*>(p.scale + n0);
-        *reinterpret_cast<float4*>(p.out + orow + n0) =
-            make_float4(rr.x + sc.x * v[0], rr.y + sc.y * v[1], rr.z + sc.z * v[2], rr.w + sc.w * v[3]);
-        continue;
-      }
-      if (EPI == SMOLTTS_EPI_QKV_ROPE) {
-        const int pos = p.row_pos[m], slot = p.row_slot[m];
-        const int qd = p.n_q_heads * 64, kd = p.n_kv_heads * 64;
-        if (n0 < qd + kd) {
-          const float4 cs = *reinterpret_cast<const float4*>(p.rope + ((long)pos * 32 + ((n0 & 63) >> 1)) * 2);
-          const float o0 = v[0] * cs.x - v[1] * cs.y, o1 = v[1] * cs.x + v[0] * cs.y;
-          const float o2 = v[2] * cs.z - v[3] * cs.w, o3 = v[3] * cs.z + v[2] * cs.w;
-          v[0] = o0; v[1] = o1; v[2] = o2; v[3] = o3;
-        }
-        const float4 o = make_float4(v[0], v[1], v[2], v[3]);
-        if (n0 < qd) {
-          *reinterpret_cast<float4*>(p.out + orow + n0) = o;
-        } else if (pos >= 0 && pos < p.cache_len) {
-          const int nn = n0 - qd;
-          float* base = nn < kd ? p.kc : p.vc;
-          const int h = (nn < kd ? nn : nn - kd) >> 6, d = nn & 63;
-          *reinterpret_cast<float4*>(base + (((long)slot * p.n_kv_heads + h) * p.cache_len + pos) * 64 + d) = o;
-        }
-        continue;
-      }
-      if (EPI == SMOLTTS_EPI_RESID) {
-        const float4 rr = *reinterpret_cast<const float4*>(p.resid + row_off(m, p.rows_per_batch, p.ldr, p.r_bstride) + n0);
-        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-      } else if (p.raw_out) {
-        *reinterpret_cast<float4*>(p.raw_out + row_off(m, p.rows_per_batch, p.ldo, p.raw_bstride) + n0) = make_float4(v[0], v[1], v[2], v[3]);
-      }
-      if (p.elu_out) { v[0] = elu1(v[0]); v[1] = elu1(v[1]); v[2] = elu1(v[2]); v[3] = elu1(v[3]); }
-      *reinterpret_cast<float4*>(p.out + orow + n0) = make_float4(v[0], v[1], v[2], v[3]);
+      rows_epilogue<EPI>(p, m, orow, n0, v);
     }
   }
 }
@@ -529,7 +446,7 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
   ST_REQUIRE(a.N >= 4 || a.epilogue == SMOLTTS_EPI_STORE, SMOLTTS_E_INVALID, "gemm: N < 4 only with EPI_STORE");
   ST_REQUIRE((long)((a.M + 63) / 64) <= 65535, SMOLTTS_E_INVALID, "gemm: M=%d too large for one launch", a.M);
   GemmDev d;
-  d.w = (const char*)a.w_dev; d.x = a.x_dev; d.ldx = a.ldx; d.x_bstride = a.x_bstride;
+  d.w = (const char*)a.w_dev; d.w3 = (const char*)a.w3_dev; d.x = a.x_dev; d.ldx = a.ldx; d.x_bstride = a.x_bstride;
   d.rows_per_batch = a.rows_per_batch; d.M = a.M; d.N = a.N; d.K = a.K; d.gamma = a.gamma_dev; d.eps = a.eps;
   d.bias = a.bias_dev; d.scale = a.scale_dev; d.resid = a.resid_dev; d.out = a.out_dev; d.ldo = a.ldo;
   d.raw_out = a.raw_out_dev; d.raw_bstride = a.raw_bstride; d.elu_out = a.elu_out;
@@ -569,6 +486,8 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
     const int WN = per >= 4 ? 4 : (per >= 2 ? 2 : 1);
     rows_grid = (long)((per + WN - 1) / WN) * ((a.M + 64 * (4 / WN) - 1) / (64 * (4 / WN)));
   }
+  if (a.w_is_fp32 && a.w3_dev && P == SMOLTTS_PRO_NONE && gemm_b3_applies(a.M, a.N, a.K, E) && !(E == SMOLTTS_EPI_STORE && a.N < 4))
+    return launch_gemm_b3(d, E, stream);
   if (a.w_is_fp32 && P == SMOLTTS_PRO_NONE && a.M >= 1024 && rows_grid >= 192) {
     ST_REQUIRE((long)((a.M + 63) / 64) <= 65535 * 4L, SMOLTTS_E_INVALID, "gemm: M=%d too large for one launch", a.M);
     switch (E) {

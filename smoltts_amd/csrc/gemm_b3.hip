@@ -1,0 +1,156 @@
+// Many-row GEMM of the Mimi decoder on the bf16 matrix cores with fp32-grade results:
+//   out[M,N] = epi( X[M,K] . W[N,K]^T ),  X fp32 rows (channel-last conv windows / Linear inputs), W fp32 weights.
+//
+// Reference ops: the Linear / Conv1d / ConvTranspose1d layers of mlx_inference/src/smoltts_mlx/codec/
+// {transformer.py:34-96, conv.py:68-220, seanet.py:99-161}, all fp32 (codec/mimi.py:107,149).
+//
+// Why: the fp32-input MFMA (v_mfma_f32_16x16x4_f32, gemm.hip) runs at 1/16 of the bf16 rate, and the SEANet
+// decoder is 337 GFLOP per 1024 frames -- 2.2 ms at that rate before anything else.  Here both operands are split
+// into three bf16 pieces (hi + mid + lo == the fp32 value exactly): the weights once on the host ("W3" tiles), the
+// activations when a chunk is staged into LDS, and six bf16 MFMAs per 32-k chunk (v_mfma_f32_16x16x32_bf16) replace
+// eight fp32 ones: 96 instead of 256 matrix-pipe cycles for the same 16x16x32 block, exact products, fp32 accumulation;
+// the three dropped cross terms are below 2^-24 relative (gemm_dev.h).
+//
+// Workgroup = 4 waves in a 2 x 2 arrangement, wave tile TM x TN MFMA tiles: 32 TM rows x 32 TN columns per
+// workgroup.  Per 32-k chunk the workgroup stages its X rows (split into pieces, B-fragment order) and its W3 tiles
+// (already in A-fragment order) in LDS once; every wave reads TM + TN fragments triples and issues 6 TM TN MFMAs;
+// the next chunk's global loads fly under them (register prefetch, one LDS buffer, two barriers per chunk).
+#include "gemm_dev.h"
+
+namespace smoltts {
+
+namespace {
+// LDS image of the X chunk: [piece][q][row] 16-byte slots; within a 16-row block, row r of plane q sits at slot
+// r ^ XS_MASK[q].  The masks map the ds_read_b128 lane-group row sets {0-3,12-15} / {4-11} onto themselves, so the
+// fragment reads (16 rows x one q per lane group half) and the staging writes (2 rows x 4 q per 8 lanes) are both
+// bank-conflict free (MI355X_MICROARCH.md, LDS table).
+__device__ __forceinline__ int xs_slot(int pc, int q, int row, int BM) {
+  const int mask = q == 0 ? 0 : (q == 1 ? 3 : (q == 2 ? 12 : 15));
+  return (pc * 4 + q) * BM + (row & ~15) + ((row & 15) ^ mask);
+}
+}  // namespace
+
+template <int TM, int TN, int EPI>
+__global__ __launch_bounds__(256) void gemm_b3_kernel(GemmDev p) {
+  constexpr int BM = 32 * TM, BN = 32 * TN, NT = BN / 16;
+  constexpr int XI = BM * 4 / 256;       // (row, q) pairs of the X chunk per thread
+  constexpr int WI = NT * 3 * 64 / 256;  // 16-byte pieces of the W3 chunk per thread
+  __shared__ uint4 xs[3 * 4 * BM];
+  __shared__ uint4 ws[NT * 3 * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nchunks = p.K >> 5;
+  const int row0 = blockIdx.y * BM, tile0 = blockIdx.x * NT;
+
+  const float* xsrc[XI];
+  int xdst[XI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int idx = tid + 256 * i, row = idx >> 2, qq = idx & 3;
+    const int m = row0 + row;
+    xsrc[i] = m < p.M ? p.x + row_off(m, p.rows_per_batch, p.ldx, p.x_bstride) + qq * 8 : nullptr;
+    xdst[i] = xs_slot(0, qq, row, BM);
+  }
+  const char* wsrc[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    const int j = tid + 256 * i, t = j / 192, rem = j - t * 192;
+    wsrc[i] = (tile0 + t) * 16 < p.N ? p.w3 + (size_t)(tile0 + t) * nchunks * 3072 + rem * 16 : nullptr;
+  }
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int t = 0; t < TN; ++t)
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 xr[XI][2];
+  uint4 wr[WI];
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      xr[i][0] = xsrc[i] ? *reinterpret_cast<const float4*>(xsrc[i] + c * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xr[i][1] = xsrc[i] ? *reinterpret_cast<const float4*>(xsrc[i] + c * 32 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) wr[i] = wsrc[i] ? *reinterpret_cast<const uint4*>(wsrc[i] + (size_t)c * 3072) : make_uint4(0, 0, 0, 0);
+  };
+  fetch(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();  // the previous chunk has been consumed
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      uint4 h, m, l;
+      split3x8(xr[i][0], xr[i][1], h, m, l);
+      xs[xdst[i]] = h;
+      xs[xdst[i] + 4 * BM] = m;
+      xs[xdst[i] + 8 * BM] = l;
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) ws[tid + 256 * i] = wr[i];
+    __syncthreads();
+    if (c + 1 < nchunks) fetch(c + 1);  // the next chunk's global loads fly under this chunk's MFMAs
+    uint4 xf[TM][3];
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) xf[mt][pc] = xs[xs_slot(pc, q, (wm * TM + mt) * 16 + r, BM)];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      uint4 wf[3];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) wf[pc] = ws[((wn * TN + t) * 3 + pc) * 64 + lane];
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt) acc[t][mt] = mfma_b3(wf, xf[mt], acc[t][mt]);
+    }
+  }
+
+  // ---- epilogue straight from the accumulators: the lane holds out[m = tile row r][n0 .. n0 + 4)
+#pragma unroll
+  for (int mt = 0; mt < TM; ++mt) {
+    const int m = row0 + (wm * TM + mt) * 16 + r;
+    if (m >= p.M) continue;
+    const long orow = row_off(m, p.rows_per_batch, p.ldo, p.o_bstride);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      float v[4] = {acc[t][mt][0], acc[t][mt][1], acc[t][mt][2], acc[t][mt][3]};
+      rows_epilogue<EPI>(p, m, orow, (tile0 + wn * TN + t) * 16 + q * 4, v);
+    }
+  }
+}
+
+// 128 x 128 tiles when that still gives every CU work, else 128 x 64, else 64 x 64
+template <int EPI>
+static int launch_b3_epi(const GemmDev& d, hipStream_t stream) {
+  auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
+  ST_REQUIRE((d.M + 63) / 64 <= 65535, SMOLTTS_E_INVALID, "gemm_b3: M=%d too large for one launch", d.M);
+  if (blocks(128, 128) >= 256 && d.N >= 128) {
+    hipLaunchKernelGGL((gemm_b3_kernel<4, 4, EPI>), dim3((d.N + 127) / 128, (d.M + 127) / 128), dim3(256), 0, stream, d);
+  } else if (blocks(128, 64) >= 256) {
+    hipLaunchKernelGGL((gemm_b3_kernel<4, 2, EPI>), dim3((d.N + 63) / 64, (d.M + 127) / 128), dim3(256), 0, stream, d);
+  } else {
+    hipLaunchKernelGGL((gemm_b3_kernel<2, 2, EPI>), dim3((d.N + 63) / 64, (d.M + 63) / 64), dim3(256), 0, stream, d);
+  }
+  ST_CHECK_HIP(hipGetLastError());
+  return SMOLTTS_OK;
+}
+
+bool gemm_b3_applies(int M, int N, int K, int epilogue) {
+  if (M < 256 || N < 64 || N % 4 != 0 || K % 32 != 0) return false;
+  return epilogue == SMOLTTS_EPI_STORE || epilogue == SMOLTTS_EPI_RESID || epilogue == SMOLTTS_EPI_GELU ||
+         epilogue == SMOLTTS_EPI_SCALE_RESID || epilogue == SMOLTTS_EPI_QKV_ROPE;
+}
+
+int launch_gemm_b3(const GemmDev& d, int epilogue, hipStream_t stream) {
+  ST_REQUIRE(d.w3 && gemm_b3_applies(d.M, d.N, d.K, epilogue), SMOLTTS_E_INVALID, "gemm_b3: shape or epilogue not supported");
+  switch (epilogue) {
+    case SMOLTTS_EPI_STORE: return launch_b3_epi<SMOLTTS_EPI_STORE>(d, stream);
+    case SMOLTTS_EPI_RESID: return launch_b3_epi<SMOLTTS_EPI_RESID>(d, stream);
+    case SMOLTTS_EPI_GELU: return launch_b3_epi<SMOLTTS_EPI_GELU>(d, stream);
+    case SMOLTTS_EPI_SCALE_RESID: return launch_b3_epi<SMOLTTS_EPI_SCALE_RESID>(d, stream);
+    default: return launch_b3_epi<SMOLTTS_EPI_QKV_ROPE>(d, stream);
+  }
+}
+
+}  // namespace smoltts

@@ -1,0 +1,121 @@
+// Device-side pieces shared by the fp32-MFMA GEMMs (gemm.hip) and the bf16x3-split many-row GEMM (gemm_b3.hip).
+#pragma once
+#include "x3.h"
+
+namespace smoltts {
+
+struct GemmDev {
+  const char* w;
+  const char* w3;  // optional: the same matrix as bf16x3 piece tiles ("W3": per 16-row x 32-k tile three 1 KiB A-fragment blocks hi|mid|lo)
+  const float* x;
+  long ldx, x_bstride;
+  int rows_per_batch;
+  int M, N, K;
+  const float* gamma;
+  float eps;
+  const float* bias;
+  const float* scale;
+  const float* resid;
+  float* out;
+  long ldo, o_bstride;
+  float* raw_out;  // optional copy of the un-activated result (same row stride, own batch stride)
+  long raw_bstride;
+  int elu_out;     // apply ELU to what goes to `out`
+  long ldr, r_bstride;
+  const float* rope;
+  const int* row_pos;
+  const int* row_slot;
+  float* kc;
+  float* vc;
+  int n_q_heads, n_kv_heads, cache_len;
+  unsigned long long* stamps;  // diagnostic build aid (SMOLTTS debug API); nullptr in production
+};
+
+__device__ __forceinline__ long row_off(int m, int rpb, long ld, long bstride) {
+  if (rpb <= 0) return (long)m * ld;
+  int b = m / rpb;
+  return (long)b * bstride + (long)(m - b * rpb) * ld;
+}
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+__device__ __forceinline__ float silu1(float x) { return x / (1.f + expf(-x)); }
+__device__ __forceinline__ float gelu1(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+// Epilogue of the many-row kernels, straight from the accumulators: the lane holds acc = X.W^T for out[m][n0 .. n0+4)
+// (`orow` = offset of row m in `out`).  Bias, then by EPI: GELU | layer-scale + residual | RoPE + q / KV-cache scatter |
+// residual and/or raw copy + optional ELU.
+template <int EPI>
+__device__ __forceinline__ void rows_epilogue(const GemmDev& p, int m, long orow, int n0, float v[4]) {
+  if (n0 >= p.N) return;
+  if (p.bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (n0 + i < p.N) v[i] += p.bias[n0 + i];
+  }
+  if (n0 + 4 > p.N) {  // N < 4: scalar tail (the 1-channel output conv)
+    for (int i = 0; i < 4 && n0 + i < p.N; ++i) p.out[orow + n0 + i] = p.elu_out ? elu1(v[i]) : v[i];
+    return;
+  }
+  if (EPI == SMOLTTS_EPI_GELU) {
+    *reinterpret_cast<float4*>(p.out + orow + n0) = make_float4(gelu1(v[0]), gelu1(v[1]), gelu1(v[2]), gelu1(v[3]));
+    return;
+  }
+  if (EPI == SMOLTTS_EPI_SCALE_RESID) {
+    const float4 rr = *reinterpret_cast<const float4*>(p.resid + row_off(m, p.rows_per_batch, p.ldr, p.r_bstride) + n0);
+    const float4 sc = *reinterpret_cast<const float4*>(p.scale + n0);
+    *reinterpret_cast<float4*>(p.out + orow + n0) =
+        make_float4(rr.x + sc.x * v[0], rr.y + sc.y * v[1], rr.z + sc.z * v[2], rr.w + sc.w * v[3]);
+    return;
+  }
+  if (EPI == SMOLTTS_EPI_QKV_ROPE) {
+    const int pos = p.row_pos[m], slot = p.row_slot[m];
+    const int qd = p.n_q_heads * 64, kd = p.n_kv_heads * 64;
+    if (n0 < qd + kd) {
+      const float4 cs = *reinterpret_cast<const float4*>(p.rope + ((long)pos * 32 + ((n0 & 63) >> 1)) * 2);
+      const float o0 = v[0] * cs.x - v[1] * cs.y, o1 = v[1] * cs.x + v[0] * cs.y;
+      const float o2 = v[2] * cs.z - v[3] * cs.w, o3 = v[3] * cs.z + v[2] * cs.w;
+      v[0] = o0; v[1] = o1; v[2] = o2; v[3] = o3;
+    }
+    const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+    if (n0 < qd) {
+      *reinterpret_cast<float4*>(p.out + orow + n0) = o;
+    } else if (pos >= 0 && pos < p.cache_len) {
+      const int nn = n0 - qd;
+      float* base = nn < kd ? p.kc : p.vc;
+      const int h = (nn < kd ? nn : nn - kd) >> 6, d = nn & 63;
+      *reinterpret_cast<float4*>(base + (((long)slot * p.n_kv_heads + h) * p.cache_len + pos) * 64 + d) = o;
+    }
+    return;
+  }
+  if (EPI == SMOLTTS_EPI_RESID) {
+    const float4 rr = *reinterpret_cast<const float4*>(p.resid + row_off(m, p.rows_per_batch, p.ldr, p.r_bstride) + n0);
+    v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+  } else if (p.raw_out) {
+    *reinterpret_cast<float4*>(p.raw_out + row_off(m, p.rows_per_batch, p.ldo, p.raw_bstride) + n0) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  if (p.elu_out) { v[0] = elu1(v[0]); v[1] = elu1(v[1]); v[2] = elu1(v[2]); v[3] = elu1(v[3]); }
+  *reinterpret_cast<float4*>(p.out + orow + n0) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// 8 consecutive fp32 values -> the three bf16x8 pieces (hi + mid + lo == the value, exactly) as packed 16-byte fragments
+__device__ __forceinline__ void split3x8(const float4 a, const float4 b, uint4& h, uint4& m, uint4& l) {
+  split3_pair(a.x, a.y, h.x, m.x, l.x);
+  split3_pair(a.z, a.w, h.y, m.y, l.y);
+  split3_pair(b.x, b.y, h.z, m.z, l.z);
+  split3_pair(b.z, b.w, h.w, m.w, l.w);
+}
+
+// acc += W . x over one 32-k chunk with both operands split in three bf16 pieces: the six products whose weight is
+// >= 2^-16 of the leading one (dropped: mid*lo, lo*mid, lo*lo, each <= 2^-24 relative: below the rounding of the fp32
+// accumulation itself), smallest first.  Products of bf16 pieces are exact in the fp32 accumulator.
+__device__ __forceinline__ f32x4 mfma_b3(const uint4 w[3], const uint4 x[3], f32x4 acc) {
+#define ST_MF(WP, XP) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[WP]), __builtin_bit_cast(bf16x8_t, x[XP]), acc, 0, 0, 0)
+  ST_MF(1, 1); ST_MF(2, 0); ST_MF(0, 2); ST_MF(1, 0); ST_MF(0, 1); ST_MF(0, 0);
+#undef ST_MF
+  return acc;
+}
+
+int launch_gemm_b3(const GemmDev& d, int epilogue, hipStream_t stream);  // gemm_b3.hip
+bool gemm_b3_applies(int M, int N, int K, int epilogue);
+
+}  // namespace smoltts

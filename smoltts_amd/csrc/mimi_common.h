@@ -24,10 +24,11 @@ int run_mimi_transformer(const char* arena, const SmolttsMimiLayerWeights* layer
 int launch_mimi_rows(int n_rows, int rows_per_slot, int pos0, int* row_pos, int* row_slot, hipStream_t st,
                      const int* slot_pos = nullptr);
 
-inline SmolttsGemmArgs mimi_gemm_f32(const void* w, const float* x, long ldx, int M, int N, int K) {
+inline SmolttsGemmArgs mimi_gemm_f32(const void* w, const float* x, long ldx, int M, int N, int K, const void* w3 = nullptr) {
   SmolttsGemmArgs a;
   memset(&a, 0, sizeof(a));
   a.w_dev = w; a.w_is_fp32 = 1; a.x_dev = x; a.ldx = ldx; a.M = M; a.N = N; a.K = K;
+  a.w3_dev = w3;  // bf16x3 piece tiles of the same matrix (many-row calls), or null
   return a;
 }
 

@@ -188,7 +188,7 @@ int run_mimi_transformer(const char* A, const SmolttsMimiLayerWeights* layers, i
     float* vc = b.vc + l * b.layer_stride;
     ST_TRY(launch_layernorm(b.tx, (const float*)(A + lw.ln1_w), (const float*)(A + lw.ln1_b), R, D, 1e-5f, b.tn, st));
     {
-      SmolttsGemmArgs a = mimi_gemm_f32(A + lw.wqkv, b.tn, D, R, 3 * D, D);
+      SmolttsGemmArgs a = mimi_gemm_f32(A + lw.wqkv, b.tn, D, R, 3 * D, D, lw.wqkv3 ? A + lw.wqkv3 : nullptr);
       a.epilogue = SMOLTTS_EPI_QKV_ROPE; a.out_dev = b.tq; a.ldo = D;
       a.rope_dev = rope; a.row_pos_dev = b.row_pos; a.row_slot_dev = b.row_slot;
       a.k_cache_dev = kc; a.v_cache_dev = vc;
@@ -197,19 +197,19 @@ int run_mimi_transformer(const char* A, const SmolttsMimiLayerWeights* layers, i
     }
     ST_TRY(launch_attention(b.tq, kc, vc, b.row_pos, b.row_slot, R, HEADS, HEADS, cache_len, window, b.ta, nullptr, st));
     {
-      SmolttsGemmArgs a = mimi_gemm_f32(A + lw.wo, b.ta, D, R, D, D);
+      SmolttsGemmArgs a = mimi_gemm_f32(A + lw.wo, b.ta, D, R, D, D, lw.wo3 ? A + lw.wo3 : nullptr);
       a.epilogue = SMOLTTS_EPI_SCALE_RESID; a.scale_dev = (const float*)(A + lw.ls1);
       a.resid_dev = b.tx; a.out_dev = b.tx; a.ldo = D;
       ST_TRY(launch_gemm(a, st));
     }
     ST_TRY(launch_layernorm(b.tx, (const float*)(A + lw.ln2_w), (const float*)(A + lw.ln2_b), R, D, 1e-5f, b.tn, st));
     {
-      SmolttsGemmArgs a = mimi_gemm_f32(A + lw.fc1, b.tn, D, R, FF, D);
+      SmolttsGemmArgs a = mimi_gemm_f32(A + lw.fc1, b.tn, D, R, FF, D, lw.fc13 ? A + lw.fc13 : nullptr);
       a.epilogue = SMOLTTS_EPI_GELU; a.out_dev = b.th; a.ldo = FF;
       ST_TRY(launch_gemm(a, st));
     }
     {
-      SmolttsGemmArgs a = mimi_gemm_f32(A + lw.fc2, b.th, FF, R, D, FF);
+      SmolttsGemmArgs a = mimi_gemm_f32(A + lw.fc2, b.th, FF, R, D, FF, lw.fc23 ? A + lw.fc23 : nullptr);
       a.epilogue = SMOLTTS_EPI_SCALE_RESID; a.scale_dev = (const float*)(A + lw.ls2);
       a.resid_dev = b.tx; a.ldr = D; a.r_bstride = (int64_t)Tt * D; a.rows_per_batch = Tt;
       a.x_bstride = (int64_t)Tt * FF;
@@ -383,7 +383,7 @@ static int decode_chunk_impl(SmolttsMimiSession* s, const int32_t* codes_dev, in
     const int Tin = BUF_RPF[i] * F;
     const int K = cv.transposed ? 2 * cv.cin : cv.k * cv.cin;
     const int N = cv.transposed ? cv.stride * cv.cout : cv.cout;
-    SmolttsGemmArgs a = mimi_gemm_f32(A + cv.w, s->buf[i], cv.cin, batch * Tin, N, K);
+    SmolttsGemmArgs a = mimi_gemm_f32(A + cv.w, s->buf[i], cv.cin, batch * Tin, N, K, cv.w3 ? A + cv.w3 : nullptr);
     a.rows_per_batch = Tin; a.x_bstride = (int64_t)s->buf_bstride[i];
     a.bias_dev = (const float*)(A + cv.b);
     a.prologue = SMOLTTS_PRO_NONE;

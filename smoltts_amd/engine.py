@@ -57,15 +57,18 @@ class GemmArgs(C.Structure):
         ("elu_out", C.c_int32), ("raw_out_dev", C.c_void_p), ("raw_bstride", C.c_int64), ("rope_dev", C.c_void_p),
         ("row_pos_dev", C.c_void_p), ("row_slot_dev", C.c_void_p), ("k_cache_dev", C.c_void_p),
         ("v_cache_dev", C.c_void_p), ("n_q_heads", C.c_int32), ("n_kv_heads", C.c_int32), ("cache_len", C.c_int32),
+        ("w3_dev", C.c_void_p),
     ]
 
 
 class MimiLayerWeights(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("ln1_w", "ln1_b", "wqkv", "wo", "ls1", "ln2_w", "ln2_b", "fc1", "fc2", "ls2")]
+    _fields_ = [(n, C.c_uint64) for n in ("ln1_w", "ln1_b", "wqkv", "wo", "ls1", "ln2_w", "ln2_b", "fc1", "fc2", "ls2",
+                                          "wqkv3", "wo3", "fc13", "fc23")]
 
 
 class MimiConv(C.Structure):
-    _fields_ = [("w", C.c_uint64), ("b", C.c_uint64)] + [(n, C.c_int32) for n in ("cin", "cout", "k", "stride", "transposed")]
+    _fields_ = [("w", C.c_uint64), ("b", C.c_uint64)] + [(n, C.c_int32) for n in ("cin", "cout", "k", "stride", "transposed")] + [
+        ("_pad", C.c_int32), ("w3", C.c_uint64)]
 
 
 class MimiConfig(C.Structure):
@@ -180,7 +183,7 @@ def load_library(path: Optional[Path] = None):
     if hasattr(lib, "smoltts_profile_begin"):  # diagnostic builds only (-DSMOLTTS_DEBUG_HOOKS)
         lib.smoltts_profile_begin.argtypes = [C.c_int32] * 4
         lib.smoltts_profile_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
-    if lib.smoltts_abi_version() != 1:
+    if lib.smoltts_abi_version() != 2:
         raise SmolttsError("libsmoltts_hip.so ABI version mismatch")
     if path is None:
         _lib = lib

@@ -14,13 +14,18 @@ from typing import Optional
 import torch
 
 from . import engine as E
-from .packing import tile_t16x32
+from .packing import tile_t16x32, tile_w3
 
 
 def pack_weight(w: torch.Tensor, fp32: bool = False) -> torch.Tensor:
     """Row-major [N, K] (CPU or GPU, any float dtype) -> T16x32 tiles on the current GPU."""
     flat = tile_t16x32(w.detach().float().cpu(), torch.float32 if fp32 else torch.bfloat16)
     return flat.cuda()
+
+
+def pack_weight_w3(w: torch.Tensor) -> torch.Tensor:
+    """Row-major fp32 [N, K] -> bf16x3 piece tiles ("W3", include/smoltts_hip.h) on the current GPU."""
+    return tile_w3(w.detach().float().cpu()).view(torch.uint8).cuda()
 
 
 def linear(x: torch.Tensor, w_tiles: torch.Tensor, N: int, *, w_fp32: bool = False, prologue: int = E.PRO_NONE,
@@ -32,7 +37,9 @@ def linear(x: torch.Tensor, w_tiles: torch.Tensor, N: int, *, w_fp32: bool = Fal
            rope: Optional[torch.Tensor] = None, row_pos: Optional[torch.Tensor] = None,
            row_slot: Optional[torch.Tensor] = None, k_cache: Optional[torch.Tensor] = None,
            v_cache: Optional[torch.Tensor] = None, n_q_heads: int = 0, n_kv_heads: int = 0, cache_len: int = 0,
-           elu_out: bool = False, raw_out: Optional[torch.Tensor] = None, raw_bstride: int = 0) -> torch.Tensor:
+           elu_out: bool = False, raw_out: Optional[torch.Tensor] = None, raw_bstride: int = 0,
+           w3: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``w3`` (``pack_weight_w3`` of the same fp32 matrix): many-row calls run the bf16x3-split kernel (gemm_b3.hip)."""
     lib = E.load_library()
     M = x.shape[0] if M is None else M
     K = x.shape[1] if K is None else K
@@ -53,6 +60,7 @@ def linear(x: torch.Tensor, w_tiles: torch.Tensor, N: int, *, w_fp32: bool = Fal
     a.rope_dev, a.row_pos_dev, a.row_slot_dev = E.dptr(rope), E.dptr(row_pos), E.dptr(row_slot)
     a.k_cache_dev, a.v_cache_dev = E.dptr(k_cache), E.dptr(v_cache)
     a.n_q_heads, a.n_kv_heads, a.cache_len = n_q_heads, n_kv_heads, cache_len
+    a.w3_dev = E.dptr(w3)
     E.check(lib.smoltts_k_gemm(C.byref(a), E.current_stream_ptr()), "smoltts_k_gemm")
     return out
 

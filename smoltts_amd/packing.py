@@ -42,6 +42,26 @@ def tile_t16x32(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return t.contiguous().reshape(-1)
 
 
+def split3_bf16(w: torch.Tensor):
+    """fp32 -> (hi, mid, lo) bf16 with hi + mid + lo == w exactly (3 x 8 significand bits), round to nearest even:
+    the split the kernels apply to activations (csrc/x3.h split3_pair)."""
+    w = w.float()
+    hi = w.to(torch.bfloat16)
+    r1 = w - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    return hi, mid, lo
+
+
+def tile_w3(w: torch.Tensor) -> torch.Tensor:
+    """Row-major fp32 [N][K] -> "W3" tiles (include/smoltts_hip.h): per 16-row x 32-k tile the three pieces' bf16 T16x32
+    blocks (1 KiB each) one after the other.  N zero-padded to 16, K % 32 == 0."""
+    N, K = w.shape
+    Np = (N + 15) // 16 * 16
+    parts = [tile_t16x32(p_, torch.bfloat16).reshape(Np // 16, K // 32, 512) for p_ in split3_bf16(w)]
+    return torch.stack(parts, dim=2).contiguous().reshape(-1)  # nt, kc, piece, 512 bf16
+
+
 FP8_MAX = 448.0  # largest finite e4m3 (OCP "fn") value
 
 
@@ -284,6 +304,9 @@ def pack_mimi(state: Dict[str, torch.Tensor], num_codebooks: int = 8, max_positi
             "fc1": ab.add(tile_t16x32(st[p + "mlp.fc1.weight"], f32)),
             "fc2": ab.add(tile_t16x32(st[p + "mlp.fc2.weight"], f32)),
             "ls2": ab.add(st[p + "mlp_layer_scale.scale"]),
+            # the same matrices as bf16x3 piece tiles: the many-row calls (chunked decode) run on the bf16 matrix cores
+            "wqkv3": ab.add(tile_w3(wqkv)), "wo3": ab.add(tile_w3(st[p + "self_attn.o_proj.weight"])),
+            "fc13": ab.add(tile_w3(st[p + "mlp.fc1.weight"])), "fc23": ab.add(tile_w3(st[p + "mlp.fc2.weight"])),
         })
     off["layers"] = layers
     convs = []
@@ -294,7 +317,7 @@ def pack_mimi(state: Dict[str, torch.Tensor], num_codebooks: int = 8, max_positi
             raise ValueError(f"decoder.layers.{key}.conv.weight has shape {tuple(w.shape)}, expected {expect}")
         gw, gb = conv_as_gemm(w, b, tr, stride)
         convs.append({"w": ab.add(tile_t16x32(gw, f32)), "b": ab.add(gb), "cin": cin, "cout": cout, "k": k,
-                      "stride": stride, "transposed": int(tr)})
+                      "stride": stride, "transposed": int(tr), "w3": ab.add(tile_w3(gw)) if gw.shape[0] >= 16 else 0})
     off["convs"] = convs
     off["n_layers"] = n_layers
     off["max_positions"] = max_positions

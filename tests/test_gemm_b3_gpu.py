@@ -1,0 +1,124 @@
+"""The bf16x3-split many-row GEMM of the Mimi decoder (csrc/gemm_b3.hip) against float64 PyTorch on the CPU.  Both operands
+are fp32 split exactly into three bf16 pieces; six of the nine piece products are kept (the rest are < 2^-24 relative), so
+the bar is the same fp32-rounding-sized tolerance as for the fp32-MFMA kernels it replaces -- and it must agree with them."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    from smoltts_amd import engine
+
+    engine.load_library()
+    return engine
+
+
+@pytest.fixture(scope="module")
+def ops(E):
+    from smoltts_amd import ops
+
+    return ops
+
+
+def rel_err(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+def test_w3_pieces_sum_exactly():
+    from smoltts_amd.packing import split3_bf16
+
+    w = torch.randn(64, 96, generator=torch.Generator().manual_seed(1)) * torch.logspace(-6, 3, 96)
+    h, m, l = split3_bf16(w)
+    assert torch.equal(h.float() + m.float() + l.float(), w)  # 3 x 8 significand bits cover fp32's 24
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 64, 32), (300, 68, 96), (2048, 1536, 512), (2048, 512, 2048), (1000, 640, 512), (4100, 256, 256),
+                                   (513, 132, 64)])
+def test_b3_store_matches_float64_and_the_fp32_kernel(E, ops, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g) * torch.logspace(-2, 2, K)[None]  # wide dynamic range across k
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    ref = x.double() @ w.double().T + b.double()
+    w32 = ops.pack_weight(w, fp32=True)
+    out = ops.linear(x.cuda(), w32, N, w_fp32=True, bias=b.cuda(), w3=ops.pack_weight_w3(w)).cpu()
+    old = ops.linear(x.cuda(), w32, N, w_fp32=True, bias=b.cuda()).cpu()
+    e_new, e_old = rel_err(out, ref), rel_err(old, ref)
+    print(f"M={M} N={N} K={K}: rel err vs float64: bf16x3 {e_new:.2e}, fp32 MFMA {e_old:.2e}")
+    assert e_new < 2e-6 and e_new < 4 * e_old + 2e-7
+
+
+def test_b3_epilogues(E, ops):
+    g = torch.Generator().manual_seed(5)
+    M, K, N = 1024, 512, 512
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+    w32, w3 = ops.pack_weight(w, fp32=True), ops.pack_weight_w3(w)
+    y = (x.double() @ w.double().T).float()
+    got = ops.linear(x.cuda(), w32, N, w_fp32=True, epilogue=E.EPI_GELU, w3=w3).cpu()
+    assert rel_err(got, F.gelu(y)) < 3e-6
+    res, sc = torch.randn(M, N, generator=g), torch.randn(N, generator=g)
+    got = ops.linear(x.cuda(), w32, N, w_fp32=True, epilogue=E.EPI_SCALE_RESID, scale=sc.cuda(), resid=res.cuda(), w3=w3).cpu()
+    assert rel_err(got, res + sc * y) < 3e-6
+    got = ops.linear(x.cuda(), w32, N, w_fp32=True, epilogue=E.EPI_RESID, resid=res.cuda(), elu_out=True, w3=w3).cpu()
+    assert rel_err(got, F.elu(res + y)) < 3e-6
+    raw = torch.zeros(M, N).cuda()
+    got = ops.linear(x.cuda(), w32, N, w_fp32=True, epilogue=E.EPI_STORE, elu_out=True, raw_out=raw, w3=w3).cpu()
+    assert rel_err(raw.cpu(), y) < 3e-6 and rel_err(got, F.elu(y)) < 3e-6
+
+
+def test_b3_qkv_rope_equals_the_fp32_kernel_layout(E, ops):
+    """Same epilogue code as the fp32 many-row kernel: q rows, K/V cache scatter, interleaved-pair rotation."""
+    g = torch.Generator().manual_seed(8)
+    M, K, H = 600, 512, 8
+    N = 3 * H * 64
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+    w32, w3 = ops.pack_weight(w, fp32=True), ops.pack_weight_w3(w)
+    slots, cache_len = 3, 256
+    pairs = torch.randperm(slots * cache_len, generator=g)[:M]
+    row_slot, row_pos = (pairs // cache_len).int().cuda(), (pairs % cache_len).int().cuda()
+    ang = torch.outer(torch.arange(cache_len).float(), 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64)))
+    rope = torch.stack([ang.cos(), ang.sin()], -1).contiguous().cuda()
+    outs = []
+    for kw in ({}, {"w3": w3}):
+        kc, vc = torch.zeros(slots, H, cache_len, 64).cuda(), torch.zeros(slots, H, cache_len, 64).cuda()
+        q = ops.linear(x.cuda(), w32, N, w_fp32=True, epilogue=E.EPI_QKV_ROPE, rope=rope, row_pos=row_pos, row_slot=row_slot,
+                       k_cache=kc, v_cache=vc, n_q_heads=H, n_kv_heads=H, cache_len=cache_len, **kw)
+        outs.append((q.cpu(), kc.cpu(), vc.cpu()))
+    for a, b in zip(*outs):
+        assert rel_err(b, a) < 3e-6
+
+
+def test_b3_conv_and_convtranspose_windows(E, ops):
+    """Convolutions as GEMMs over halo-prefixed channel-last rows (per-slot strides, rows_per_batch), fused ELU + raw copy."""
+    from smoltts_amd.packing import conv_as_gemm
+
+    g = torch.Generator().manual_seed(21)
+    B, T, cin, cout, k = 3, 400, 256, 128, 3
+    x = torch.randn(B, cin, T, generator=g)
+    w, b = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k), torch.randn(cout, generator=g)
+    ref = F.conv1d(F.pad(x, (k - 1, 0)).double(), w.double(), b.double()).transpose(1, 2)
+    buf = torch.zeros(B, k - 1 + T, cin)
+    buf[:, k - 1:] = x.transpose(1, 2)
+    gw, gb = conv_as_gemm(w, b, False, 1)
+    out, raw = torch.zeros(B, T, cout).cuda(), torch.zeros(B, T, cout).cuda()
+    ops.linear(buf.cuda(), ops.pack_weight(gw, fp32=True), cout, w_fp32=True, epilogue=E.EPI_STORE, bias=gb.cuda(), out=out, M=B * T,
+               K=k * cin, ldx=cin, x_bstride=(k - 1 + T) * cin, rows_per_batch=T, ldo=cout, o_bstride=T * cout, elu_out=True,
+               raw_out=raw, raw_bstride=T * cout, w3=ops.pack_weight_w3(gw))
+    assert rel_err(raw.cpu(), ref) < 3e-6 and rel_err(out.cpu(), F.elu(ref)) < 3e-6
+    B, T, cin, cout, s = 3, 700, 128, 64, 4
+    x = torch.randn(B, cin, T, generator=g)
+    w, b = torch.randn(cin, cout, 2 * s, generator=g) / math.sqrt(cin), torch.randn(cout, generator=g)
+    y = F.conv_transpose1d(x.double(), w.double(), b.double(), stride=s)
+    ref = y[..., : y.shape[-1] - s].transpose(1, 2)
+    buf = torch.zeros(B, 1 + T, cin)
+    buf[:, 1:] = x.transpose(1, 2)
+    gw, gb = conv_as_gemm(w, b, True, s)
+    out = torch.zeros(B, T * s, cout).cuda()
+    ops.linear(buf.cuda(), ops.pack_weight(gw, fp32=True), s * cout, w_fp32=True, epilogue=E.EPI_STORE, bias=gb.cuda(), out=out, M=B * T,
+               K=2 * cin, ldx=cin, x_bstride=(1 + T) * cin, rows_per_batch=T, ldo=s * cout, o_bstride=T * s * cout, w3=ops.pack_weight_w3(gw))
+    assert rel_err(out.cpu(), ref) < 3e-6
