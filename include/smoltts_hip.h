@@ -230,6 +230,8 @@ typedef struct SmolttsMimiWeights {
   SmolttsMimiLayerWeights layers[SMOLTTS_MIMI_MAX_LAYERS];
   SmolttsMimiConv convs[14]; /* SEANet decoder in execution order: conv0, then per ratio
                                 (convtr, res.conv3, res.conv1) x4, then the final conv (14 in all) */
+  uint64_t final_w;          /* fp32 [3][64]: the output conv (64 -> 1, k3) tap-major, for the fused last stage; its bias is
+                                convs[13].b */
 } SmolttsMimiWeights;
 
 typedef struct SmolttsMimi SmolttsMimi;

@@ -27,7 +27,11 @@ constexpr int SAMPLES = 1920;
 // buffer i feeds conv i (i < 13); channels, halo rows and rows per frame of each conv input
 // conv order: conv0 | convT1 res1.c3 res1.c1 | convT2 ... | convT4 res4.c3 res4.c1 | final
 constexpr int BUF_C[NBUF] = {512, 1024, 512, 256, 512, 256, 128, 256, 128, 64, 128, 64, 32, 64};
-constexpr int BUF_HALO[NBUF] = {6, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 2};
+// Stages 3 and 4 run their resnet block fused (seanet.hip): buffers 8 and 11 then hold the RAW ConvTranspose output (the block
+// recomputes ELU and the rows it needs of the previous tile), buffer 11 with 4 halo rows (2 for the block's k3 conv + 2 for the
+// output conv applied in the same kernel); buffers 9, 12, 13 are unused.
+constexpr int BUF_HALO[NBUF] = {6, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 4, 0, 2};
+constexpr bool FUSED_BLOCK[NCONV] = {false, false, false, false, false, false, false, false, true, false, false, true, false, false};
 constexpr int BUF_RPF[NBUF] = {2, 2, 16, 16, 16, 96, 96, 96, 480, 480, 480, 1920, 1920, 1920};
 // buffer index feeding each conv (conv c reads BUF[c]; writes BUF[c+1], the last writes pcm)
 }  // namespace
@@ -55,6 +59,7 @@ struct SmolttsMimiSession {
   size_t zero_bytes;
   int* pos_dev;      // [B] transformer positions consumed so far, per slot (slots are reset independently when streams
                      // of different utterances share the session)
+  float final_bias;  // bias of the output conv (read from the arena once, at session creation)
   int* pos_host;     // host mirror (deterministic: += 2 * frames per call for the slots decoded, 0 on reset)
   int parity;
 };
@@ -237,7 +242,7 @@ int smoltts_mimi_create(const SmolttsMimiConfig* cfg, const SmolttsMimiWeights* 
   for (int i = 0; i < NCONV; ++i) {
     const SmolttsMimiConv& cv = offsets->convs[i];
     ST_REQUIRE(cv.cin == BUF_C[i] && (i + 1 == NCONV ? cv.cout == 1 : (cv.transposed ? cv.cout : cv.cout) == BUF_C[i + 1]) &&
-                   (cv.transposed ? (cv.k == 2 * cv.stride && BUF_HALO[i] == 1) : (cv.stride == 1 && BUF_HALO[i] == cv.k - 1)) && cv.w % 16 == 0 && cv.b % 16 == 0 && cv.w < arena_bytes && cv.b < arena_bytes,
+                   (cv.transposed ? (cv.k == 2 * cv.stride && BUF_HALO[i] == 1) : (cv.stride == 1 && (FUSED_BLOCK[i] || BUF_HALO[i] == cv.k - 1))) && cv.w % 16 == 0 && cv.b % 16 == 0 && cv.w < arena_bytes && cv.b < arena_bytes,
                SMOLTTS_E_INVALID, "mimi_create: conv %d descriptor inconsistent (cin=%d)", i, cv.cin);
   }
   ST_REQUIRE(offsets->rvq_table + (size_t)cfg->num_codebooks * 2048 * D * 4 <= arena_bytes &&
@@ -277,7 +282,8 @@ int smoltts_mimi_session_create(SmolttsMimi* m, void* slab_dev, size_t slab_byte
   size_t total = 0;
   carve(s, (char*)slab_dev, &total);
   s->pos_host = static_cast<int*>(calloc((size_t)max_batch, sizeof(int)));
-  if (s->pos_host == nullptr || hipMemset(s->zero_begin, 0, s->zero_bytes) != hipSuccess) {
+  if (s->pos_host == nullptr || hipMemset(s->zero_begin, 0, s->zero_bytes) != hipSuccess ||
+      hipMemcpy(&s->final_bias, m->arena + m->w.convs[NCONV - 1].b, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
     free(s->pos_host);
     delete s;
     set_error("mimi_session_create: allocation or hipMemset failed");
@@ -380,6 +386,25 @@ static int decode_chunk_impl(SmolttsMimiSession* s, const int32_t* codes_dev, in
   //    beside it for the resnet block's residual add.
   for (int i = 0; i < NCONV; ++i) {
     const SmolttsMimiConv& cv = m->w.convs[i];
+    if (FUSED_BLOCK[i]) {  // resnet block i, i+1 (and, for the last stage, the output conv i+2) in one kernel
+      const SmolttsMimiConv& c1 = m->w.convs[i + 1];
+      const bool last = i + 3 == NCONV;
+      ST_REQUIRE(cv.w3 && c1.w3 && (!last || m->w.final_w), SMOLTTS_E_INVALID, "mimi: the arena lacks the W3 tiles of conv %d", i);
+      MimiResblockArgs a;
+      memset(&a, 0, sizeof(a));
+      a.channels = cv.cin; a.final_conv = last; a.batch = batch; a.T = BUF_RPF[i] * F;
+      a.x = s->buf[i] + (size_t)BUF_HALO[i] * BUF_C[i]; a.x_bstride = (int64_t)s->buf_bstride[i];
+      a.w2 = A + cv.w3; a.b2 = (const float*)(A + cv.b); a.w3 = A + c1.w3; a.b3 = (const float*)(A + c1.b);
+      if (last) {
+        a.final_w = (const float*)(A + m->w.final_w); a.final_b = s->final_bias; a.pcm = pcm_dev; a.pcm_stride = pcm_stride;
+        a.slot_pos = s->pos_dev;
+      } else {
+        a.out = s->buf[i + 2] + (size_t)BUF_HALO[i + 2] * BUF_C[i + 2]; a.o_bstride = (int64_t)s->buf_bstride[i + 2];
+      }
+      ST_TRY(launch_seanet_resblock(a, st));
+      i += last ? 2 : 1;
+      continue;
+    }
     const int Tin = BUF_RPF[i] * F;
     const int K = cv.transposed ? 2 * cv.cin : cv.k * cv.cin;
     const int N = cv.transposed ? cv.stride * cv.cout : cv.cout;
@@ -391,11 +416,11 @@ static int decode_chunk_impl(SmolttsMimiSession* s, const int32_t* codes_dev, in
     if (i + 1 < NCONV) {
       a.out_dev = s->buf[i + 1] + (size_t)BUF_HALO[i + 1] * BUF_C[i + 1];
       a.ldo = N; a.o_bstride = (int64_t)s->buf_bstride[i + 1];
-      a.elu_out = 1;
+      a.elu_out = FUSED_BLOCK[i + 1] ? 0 : 1;  // a fused block takes the raw tensor
     } else {
       a.out_dev = pcm_dev; a.ldo = 1; a.o_bstride = pcm_stride;
     }
-    if (cv.transposed) {  // i = 1, 4, 7, 10 -> raw copy j = (i - 1) / 3
+    if (cv.transposed && !FUSED_BLOCK[i + 1]) {  // i = 1, 4 -> raw copy j = (i - 1) / 3 for the (unfused) block's residual
       const int j = (i - 1) / 3;
       a.raw_out_dev = s->raw[j]; a.raw_bstride = (int64_t)s->raw_bstride[j];
     }

@@ -1,0 +1,269 @@
+// Fused SEANet resnet block (and, for the last stage, the output convolution) of the Mimi decoder.
+//
+// Reference: MimiResnetBlock (mlx_inference/src/smoltts_mlx/codec/seanet.py:8-49, dilation 1):
+//   y = x + Conv1d_k1( ELU( Conv1d_k3( ELU(x) ) ) ),   C -> C/2 -> C channels, causal (left zero padding of ELU(x)),
+// followed in MimiDecoder (seanet.py:99-139) by ELU and either the next ConvTranspose1d or, after the last block,
+// Conv1d k3 (64 -> 1) to PCM.
+//
+// Unfused, the two late stages move the block's tensors through HBM five times per 1024 frames (raw + ELU copy of x, the
+// hidden, y, the residual re-read: ~3.5 GB at 64 channels x 1.97 M rows, ~1.8 GB at 128 x 0.49 M) for 10 % of the FLOPs.
+// Here one workgroup takes RC consecutive rows of one slot: x (raw ConvTranspose output) is read once, ELU(x) is split
+// into bf16x3 pieces in LDS (gemm_dev.h: fp32-grade products on the bf16 matrix cores), both convolutions run as
+// 16x16x32 MFMAs over LDS-resident operands with the weights staged through LDS in groups of 32-k chunks, the hidden
+// never leaves LDS, and only ELU(y) -- or, in the last stage, the PCM samples -- is written.  The causal k3 windows of
+// a tile need 2 rows (4 with the output conv) of the previous tile: recomputed from x, whose halo rows in front of the
+// buffer carry the previous call's last rows (streaming), so chunked decoding equals decoding in one call.
+#include "gemm_dev.h"
+#include "mimi_common.h"
+
+namespace smoltts {
+
+namespace {
+
+struct ResDev {
+  const float* x;   // raw block input, row 0 of slot 0; HX = 2 (4 with FINAL) halo rows sit in front of every slot's rows
+  long x_bstride;   // floats per slot
+  int T;            // rows per slot in this call
+  const char* w2;   // conv k3, C -> C/2, as W3 tiles of the GEMM matrix [C/2][3C] (k = tap * C + channel)
+  const float* b2;
+  const char* w3;   // conv k1, C/2 -> C, as W3 tiles of [C][C/2]
+  const float* b3;
+  float* out;       // !FINAL: ELU(y), row 0 of slot 0 of the next stage's input buffer
+  long o_bstride;
+  const float* wf;  // FINAL: output conv k3, C -> 1: fp32 [3][C] (tap-major), bias bf
+  float bf;
+  float* pcm;
+  long pcm_stride;
+  const int* slot_pos;  // FINAL: [slots] stream position before this call (0: the stream starts here -> rows before it are padding)
+};
+
+template <int C, int RC, bool FINAL>
+struct ResCfg {
+  static constexpr int H = C / 2, HY = FINAL ? 2 : 0, RT = RC - HY, RL = RC + 2, RLP = (RL + 15) / 16 * 16;
+  static constexpr int CC = C / 32, HC = H / 32, K2C = 3 * CC;
+  static constexpr int NT2 = H / 16, NT3 = C / 16, MT = RC / 16;
+  static constexpr int WR = MT < 8 ? MT : 8, WC = 8 / WR;  // wave arrangement: row tiles x column groups
+  static constexpr int HP_U4 = 3 * CC * 4 * RLP, VP_U4 = 3 * HC * 4 * RC;
+  static constexpr int WB_BYTES = C == 64 ? 36864 : 24576;
+  static constexpr int GK2 = NT2 * K2C * 3072 <= WB_BYTES ? K2C : WB_BYTES / (NT2 * 3072);
+  static constexpr int GK3 = NT3 * HC * 3072 <= WB_BYTES ? HC : WB_BYTES / (NT3 * 3072);
+  static constexpr size_t LDS = (size_t)(HP_U4 + VP_U4) * 16 + WB_BYTES;
+  static_assert(MT % WR == 0 && 8 % WR == 0 && NT2 % WC == 0 && NT3 % WC == 0, "wave arrangement");
+  static_assert(K2C % GK2 == 0 && HC % GK3 == 0 && GK2 >= 1 && GK3 >= 1, "weight groups");
+  static_assert(!FINAL || (RC * C * 4 <= HP_U4 * 16 && 4 * RT <= 512), "FINAL: ELU(y) aliases the ELU(x) pieces; 4 threads per sample");
+};
+
+template <int C, int RC, bool FINAL>
+__global__ __launch_bounds__(512) void resblock_kernel(ResDev p) {
+  using K = ResCfg<C, RC, FINAL>;
+  constexpr int H = K::H, HY = K::HY, RT = K::RT, RL = K::RL, RLP = K::RLP, CC = K::CC, HC = K::HC, K2C = K::K2C;
+  constexpr int NT2 = K::NT2, NT3 = K::NT3, MT = K::MT, WR = K::WR, WC = K::WC;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* hp = reinterpret_cast<uint4*>(smem);                  // ELU(x) pieces [piece][x chunk][q][row]
+  uint4* vp = hp + K::HP_U4;                                   // ELU(hidden) pieces [piece][h chunk][q][row]
+  uint4* wb = vp + K::VP_U4;                                   // weight group [col tile][chunk in group][piece][lane]
+  float* ey = reinterpret_cast<float*>(smem);                  // FINAL: ELU(y) [row][C], over the (dead) ELU(x) pieces
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int b = blockIdx.y;
+  const int u0 = blockIdx.x * RT;   // first output row of the tile
+  const int cu0 = u0 - HY;          // first computed row (y); x rows cu0 - 2 .. cu0 + RC - 1 are loaded
+  const float* xb = p.x + (long)b * p.x_bstride;
+  const int wr = wave % WR, wc = wave / WR;
+
+  auto stage_w = [&](const char* wsrc, int NT, int KC, int k0, int gk) {  // gk chunks of every column tile -> wb
+    const int n16 = NT * gk * 192;
+    for (int j = tid; j < n16; j += 512) {
+      const int blk = j / 192, rem = j - blk * 192, nt = blk / gk, kcl = blk - nt * gk;
+      wb[j] = *reinterpret_cast<const uint4*>(wsrc + (size_t)(nt * KC + k0 + kcl) * 3072 + rem * 16);
+    }
+  };
+
+  // ---- phase 0: x -> ELU -> bf16x3 pieces in LDS (the first weight group rides along)
+  for (int idx = tid; idx < RL * (C / 8); idx += 512) {
+    const int lr = idx / (C / 8), g8 = idx - lr * (C / 8);
+    const int row = cu0 - 2 + lr;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+    if (row < p.T) {
+      const float* src = xb + (long)row * C + g8 * 8;
+      a = *reinterpret_cast<const float4*>(src);
+      c = *reinterpret_cast<const float4*>(src + 4);
+    }
+    a = make_float4(elu1(a.x), elu1(a.y), elu1(a.z), elu1(a.w));
+    c = make_float4(elu1(c.x), elu1(c.y), elu1(c.z), elu1(c.w));
+    uint4 h, m, l;
+    split3x8(a, c, h, m, l);
+    const int slot = ((g8 >> 2) * 4 + (g8 & 3)) * RLP + lr;  // [x chunk][q][row] inside a piece plane
+    hp[slot] = h;
+    hp[slot + CC * 4 * RLP] = m;
+    hp[slot + 2 * CC * 4 * RLP] = l;
+  }
+  stage_w(p.w2, NT2, K2C, 0, K::GK2);
+  __syncthreads();
+
+  // ---- phase B: hidden = conv k3 over ELU(x): out row i reads ELU(x) local rows i, i+1, i+2 (taps 0..2)
+  {
+    constexpr int RW = MT / WR, CW = NT2 / WC;
+    f32x4 acc[RW][CW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+      for (int j = 0; j < CW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < K2C / K::GK2; ++g) {
+      if (g > 0) {
+        __syncthreads();
+        stage_w(p.w2, NT2, K2C, g * K::GK2, K::GK2);
+        __syncthreads();
+      }
+#pragma unroll
+      for (int kcl = 0; kcl < K::GK2; ++kcl) {
+        const int kc = g * K::GK2 + kcl, tap = kc / CC, xc = kc - tap * CC;
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+          const int mt = wr + i * WR;
+          uint4 xf[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) xf[pc] = hp[((pc * CC + xc) * 4 + q) * RLP + mt * 16 + r + tap];
+#pragma unroll
+          for (int j = 0; j < CW; ++j) {
+            uint4 wf[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) wf[pc] = wb[(((wc * CW + j) * K::GK2 + kcl) * 3 + pc) * 64 + lane];
+            acc[i][j] = mfma_b3(wf, xf, acc[i][j]);
+          }
+        }
+      }
+    }
+    // hidden + bias -> ELU -> pieces: the lane holds hidden[row mt*16 + r][n = ct*16 + 4q .. +4)
+    uint2* vp2 = reinterpret_cast<uint2*>(vp);
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+      for (int j = 0; j < CW; ++j) {
+        const int row = (wr + i * WR) * 16 + r, ct = wc * CW + j, n = ct * 16 + 4 * q;
+        const float4 bb = *reinterpret_cast<const float4*>(p.b2 + n);
+        const float v0 = elu1(acc[i][j][0] + bb.x), v1 = elu1(acc[i][j][1] + bb.y), v2 = elu1(acc[i][j][2] + bb.z), v3 = elu1(acc[i][j][3] + bb.w);
+        uint32_t h0, m0, l0, h1, m1, l1;
+        split3_pair(v0, v1, h0, m0, l0);
+        split3_pair(v2, v3, h1, m1, l1);
+        const int hc = ct >> 1, qv = (ct & 1) * 2 + (q >> 1);
+        const int s2 = ((hc * 4 + qv) * RC + row) * 2 + (q & 1);  // 8-byte half of the row's 16-byte slot
+        vp2[s2] = make_uint2(h0, h1);
+        vp2[s2 + HC * 4 * RC * 2] = make_uint2(m0, m1);
+        vp2[s2 + 2 * HC * 4 * RC * 2] = make_uint2(l0, l1);
+      }
+  }
+
+  // ---- phase C: y = conv k1 over ELU(hidden) + x
+  const bool stream_start = FINAL && p.slot_pos[b] == 0 && blockIdx.x == 0;
+  {
+    constexpr int RW = MT / WR, CW = NT3 / WC;
+    f32x4 acc[RW][CW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+      for (int j = 0; j < CW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < HC / K::GK3; ++g) {
+      __syncthreads();  // phase B (or the previous group) is done with wb; the hidden pieces are complete
+      stage_w(p.w3, NT3, HC, g * K::GK3, K::GK3);
+      __syncthreads();
+#pragma unroll
+      for (int kcl = 0; kcl < K::GK3; ++kcl) {
+        const int kc = g * K::GK3 + kcl;
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+          const int mt = wr + i * WR;
+          uint4 xf[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) xf[pc] = vp[((pc * HC + kc) * 4 + q) * RC + mt * 16 + r];
+#pragma unroll
+          for (int j = 0; j < CW; ++j) {
+            uint4 wf[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) wf[pc] = wb[(((wc * CW + j) * K::GK3 + kcl) * 3 + pc) * 64 + lane];
+            acc[i][j] = mfma_b3(wf, xf, acc[i][j]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int row = (wr + i * WR) * 16 + r, grow = cu0 + row;
+#pragma unroll
+      for (int j = 0; j < CW; ++j) {
+        const int n = (wc * CW + j) * 16 + 4 * q;
+        float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grow < p.T) {
+          const float4 xr = *reinterpret_cast<const float4*>(xb + (long)grow * C + n);  // the residual: x again (L2)
+          const float4 bb = *reinterpret_cast<const float4*>(p.b3 + n);
+          e = make_float4(elu1(acc[i][j][0] + bb.x + xr.x), elu1(acc[i][j][1] + bb.y + xr.y), elu1(acc[i][j][2] + bb.z + xr.z),
+                          elu1(acc[i][j][3] + bb.w + xr.w));
+        }
+        if (FINAL) {
+          if (stream_start && grow < 0) e = make_float4(0.f, 0.f, 0.f, 0.f);  // before the stream: the output conv's zero padding
+          *reinterpret_cast<float4*>(ey + row * C + n) = e;
+        } else if (grow < p.T) {
+          *reinterpret_cast<float4*>(p.out + (long)b * p.o_bstride + (long)grow * C + n) = e;
+        }
+      }
+    }
+  }
+
+  // ---- phase D (last stage): PCM sample u0 + i = bf + sum_{tap, c} wf[tap][c] * ELU(y)[i + tap][c]; 4 threads per sample
+  if (FINAL) {
+    __syncthreads();
+    const int i = tid >> 2, part = tid & 3;
+    float s = 0.f;
+    if (i < RT) {
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap) {
+        const float* er = ey + (i + tap) * C + part * (C / 4);
+        const float* wr_ = p.wf + tap * C + part * (C / 4);
+#pragma unroll
+        for (int c4 = 0; c4 < C / 16; ++c4) {
+          const float4 ev = *reinterpret_cast<const float4*>(er + c4 * 4);
+          const float4 wv = *reinterpret_cast<const float4*>(wr_ + c4 * 4);
+          s = fmaf(ev.x, wv.x, s); s = fmaf(ev.y, wv.y, s); s = fmaf(ev.z, wv.z, s); s = fmaf(ev.w, wv.w, s);
+        }
+      }
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (i < RT && part == 0 && u0 + i < p.T) p.pcm[(long)b * p.pcm_stride + u0 + i] = s + p.bf;
+  }
+}
+
+template <int C, int RC, bool FINAL>
+int launch_res(const ResDev& d, int batch, hipStream_t st) {
+  using K = ResCfg<C, RC, FINAL>;
+  static bool attr_set = false;
+  if (!attr_set) {  // > 64 KB of dynamic LDS must be requested once per kernel
+    ST_CHECK_HIP(hipFuncSetAttribute((const void*)resblock_kernel<C, RC, FINAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS));
+    attr_set = true;
+  }
+  const dim3 grid((d.T + K::RT - 1) / K::RT, batch);
+  ST_REQUIRE(grid.y <= 65535, SMOLTTS_E_INVALID, "resblock: batch too large");
+  hipLaunchKernelGGL((resblock_kernel<C, RC, FINAL>), grid, dim3(512), K::LDS, st, d);
+  ST_CHECK_HIP(hipGetLastError());
+  return SMOLTTS_OK;
+}
+
+}  // namespace
+
+int launch_seanet_resblock(const MimiResblockArgs& a, hipStream_t st) {
+  ST_REQUIRE(a.x && a.w2 && a.b2 && a.w3 && a.b3 && a.T > 0 && a.batch > 0, SMOLTTS_E_INVALID, "resblock: null or empty argument");
+  ResDev d{a.x, (long)a.x_bstride, a.T, (const char*)a.w2, a.b2, (const char*)a.w3, a.b3, a.out, (long)a.o_bstride,
+           a.final_w, a.final_b, a.pcm, (long)a.pcm_stride, a.slot_pos};
+  if (a.channels == 128 && !a.final_conv) {
+    ST_REQUIRE(a.out, SMOLTTS_E_INVALID, "resblock: null output");
+    return launch_res<128, 64, false>(d, a.batch, st);
+  }
+  if (a.channels == 64 && a.final_conv) {
+    ST_REQUIRE(a.final_w && a.pcm && a.slot_pos, SMOLTTS_E_INVALID, "resblock: the last stage needs the output conv, pcm and slot positions");
+    return launch_res<64, 128, true>(d, a.batch, st);
+  }
+  set_error("resblock: no instance for %d channels, final_conv=%d", a.channels, a.final_conv);
+  return SMOLTTS_E_INVALID;
+}
+
+}  // namespace smoltts

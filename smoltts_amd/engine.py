@@ -77,7 +77,7 @@ class MimiConfig(C.Structure):
 
 class MimiWeights(C.Structure):
     _fields_ = [("rvq_table", C.c_uint64), ("upsample_w", C.c_uint64), ("rope", C.c_uint64),
-                ("layers", MimiLayerWeights * MIMI_MAX_LAYERS), ("convs", MimiConv * 14)]
+                ("layers", MimiLayerWeights * MIMI_MAX_LAYERS), ("convs", MimiConv * 14), ("final_w", C.c_uint64)]
 
 
 class MimiEncConfig(C.Structure):
@@ -488,6 +488,7 @@ class MimiEngine:
         cfg = MimiConfig(num_codebooks, off["n_layers"], window, max_positions)
         w = MimiWeights()
         w.rvq_table, w.upsample_w, w.rope = off["rvq_table"], off["upsample_w"], off["rope"]
+        w.final_w = off["final_w"]
         for i, l in enumerate(off["layers"]):
             for k, v in l.items():
                 setattr(w.layers[i], k, v)

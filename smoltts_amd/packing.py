@@ -319,6 +319,10 @@ def pack_mimi(state: Dict[str, torch.Tensor], num_codebooks: int = 8, max_positi
         convs.append({"w": ab.add(tile_t16x32(gw, f32)), "b": ab.add(gb), "cin": cin, "cout": cout, "k": k,
                       "stride": stride, "transposed": int(tr), "w3": ab.add(tile_w3(gw)) if gw.shape[0] >= 16 else 0})
     off["convs"] = convs
+    # the output conv (64 -> 1, k3) once more as plain fp32 [3][64] (tap-major): the fused last SEANet stage applies it on the
+    # vector units to the block's output while that is still in LDS
+    fw, _ = conv_as_gemm(st["decoder.layers.14.conv.weight"], st["decoder.layers.14.conv.bias"], False, 1)
+    off["final_w"] = ab.add(fw.reshape(-1).contiguous())
     off["n_layers"] = n_layers
     off["max_positions"] = max_positions
     return ab.finish(), off
