@@ -37,25 +37,34 @@ struct ResDev {
   const int* slot_pos;  // FINAL: [slots] stream position before this call (0: the stream starts here -> rows before it are padding)
 };
 
-template <int C, int RC, bool FINAL>
+// Tiles are kept small on purpose: a tile is a chain of dependent memory round trips (x, weight groups, residual) with
+// barriers in between, so what hides the latency is several workgroups per CU (LDS is the limit: 37-74 KB per workgroup),
+// at the price of re-reading the (L2-resident) weights once per tile.
+// ELU with the hardware exponential: exp(x) - 1 carries an absolute error of ~1 ulp of 1 (6e-8) where expm1f is relatively
+// exact -- the size of the fp32 rounding of the O(1) activations around it, at a fifth of the instructions (the block applies
+// ELU to every element of x, of the hidden and of y: with expm1f the vector units, not the matrix cores, bound the kernel).
+__device__ __forceinline__ float elu_fast(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
+
+template <int C, int RC, bool FINAL, int NW>
 struct ResCfg {
   static constexpr int H = C / 2, HY = FINAL ? 2 : 0, RT = RC - HY, RL = RC + 2, RLP = (RL + 15) / 16 * 16;
   static constexpr int CC = C / 32, HC = H / 32, K2C = 3 * CC;
   static constexpr int NT2 = H / 16, NT3 = C / 16, MT = RC / 16;
-  static constexpr int WR = MT < 8 ? MT : 8, WC = 8 / WR;  // wave arrangement: row tiles x column groups
+  static constexpr int WR = MT < NW ? MT : NW, WC = NW / WR;  // wave arrangement: row tiles x column groups
   static constexpr int HP_U4 = 3 * CC * 4 * RLP, VP_U4 = 3 * HC * 4 * RC;
-  static constexpr int WB_BYTES = C == 64 ? 36864 : 24576;
-  static constexpr int GK2 = NT2 * K2C * 3072 <= WB_BYTES ? K2C : WB_BYTES / (NT2 * 3072);
-  static constexpr int GK3 = NT3 * HC * 3072 <= WB_BYTES ? HC : WB_BYTES / (NT3 * 3072);
+  static constexpr int GK3 = 1;                                   // conv k1: one 32-k chunk of all its column tiles at a time
+  static constexpr int WB_BYTES = NT3 * 3072 > 12288 ? NT3 * 3072 : 12288;
+  static constexpr int GK2 = (WB_BYTES / (NT2 * 3072)) >= K2C ? K2C : ((WB_BYTES / (NT2 * 3072)) >= 2 ? 2 : 1);
   static constexpr size_t LDS = (size_t)(HP_U4 + VP_U4) * 16 + WB_BYTES;
-  static_assert(MT % WR == 0 && 8 % WR == 0 && NT2 % WC == 0 && NT3 % WC == 0, "wave arrangement");
-  static_assert(K2C % GK2 == 0 && HC % GK3 == 0 && GK2 >= 1 && GK3 >= 1, "weight groups");
-  static_assert(!FINAL || (RC * C * 4 <= HP_U4 * 16 && 4 * RT <= 512), "FINAL: ELU(y) aliases the ELU(x) pieces; 4 threads per sample");
+  static_assert(MT % WR == 0 && NW % WR == 0 && NT2 % WC == 0 && NT3 % WC == 0, "wave arrangement");
+  static_assert(K2C % GK2 == 0 && NT2 * GK2 * 3072 <= WB_BYTES && NT3 * GK3 * 3072 <= WB_BYTES, "weight groups");
+  static_assert(!FINAL || (RC * C * 4 <= HP_U4 * 16 && 4 * RT <= NW * 64), "FINAL: ELU(y) aliases the ELU(x) pieces; 4 threads per sample");
 };
 
-template <int C, int RC, bool FINAL>
-__global__ __launch_bounds__(512) void resblock_kernel(ResDev p) {
-  using K = ResCfg<C, RC, FINAL>;
+template <int C, int RC, bool FINAL, int NW>
+__global__ __launch_bounds__(NW * 64) void resblock_kernel(ResDev p) {
+  using K = ResCfg<C, RC, FINAL, NW>;
+  constexpr int NTHR = NW * 64;
   constexpr int H = K::H, HY = K::HY, RT = K::RT, RL = K::RL, RLP = K::RLP, CC = K::CC, HC = K::HC, K2C = K::K2C;
   constexpr int NT2 = K::NT2, NT3 = K::NT3, MT = K::MT, WR = K::WR, WC = K::WC;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -71,16 +80,28 @@ __global__ __launch_bounds__(512) void resblock_kernel(ResDev p) {
   const float* xb = p.x + (long)b * p.x_bstride;
   const int wr = wave % WR, wc = wave / WR;
 
-  auto stage_w = [&](const char* wsrc, int NT, int KC, int k0, int gk) {  // gk chunks of every column tile -> wb
-    const int n16 = NT * gk * 192;
-    for (int j = tid; j < n16; j += 512) {
-      const int blk = j / 192, rem = j - blk * 192, nt = blk / gk, kcl = blk - nt * gk;
-      wb[j] = *reinterpret_cast<const uint4*>(wsrc + (size_t)(nt * KC + k0 + kcl) * 3072 + rem * 16);
-    }
-  };
+  // Weight groups go global -> registers -> LDS so that the L2 round trip of the next group hides behind the MFMAs of the
+  // current one: GK chunks of every column tile = NT * GK * 192 16-byte pieces, WPT per thread (compile-time shapes: the
+  // register array must never become addressable).
+  constexpr int WPT = (K::WB_BYTES / 16 + NTHR - 1) / NTHR;
+  uint4 wreg[WPT];
+#define ST_FETCH_W(WSRC, NT, KC, K0, GK)                                                                          \
+  _Pragma("unroll") for (int t_ = 0; t_ < WPT; ++t_) {                                                            \
+    const int j_ = tid + t_ * NTHR;                                                                               \
+    const int blk_ = j_ / 192, rem_ = j_ - blk_ * 192, nt_ = blk_ / (GK), kcl_ = blk_ - nt_ * (GK);              \
+    wreg[t_] = j_ < (NT) * (GK) * 192                                                                             \
+                   ? *reinterpret_cast<const uint4*>((WSRC) + (size_t)(nt_ * (KC) + (K0) + kcl_) * 3072 + rem_ * 16) \
+                   : make_uint4(0, 0, 0, 0);                                                                      \
+  }
+#define ST_STORE_W(NT, GK)                                                                                        \
+  _Pragma("unroll") for (int t_ = 0; t_ < WPT; ++t_) {                                                            \
+    const int j_ = tid + t_ * NTHR;                                                                               \
+    if (j_ < (NT) * (GK) * 192) wb[j_] = wreg[t_];                                                                \
+  }
 
   // ---- phase 0: x -> ELU -> bf16x3 pieces in LDS (the first weight group rides along)
-  for (int idx = tid; idx < RL * (C / 8); idx += 512) {
+  ST_FETCH_W(p.w2, NT2, K2C, 0, K::GK2)
+  for (int idx = tid; idx < RL * (C / 8); idx += NTHR) {
     const int lr = idx / (C / 8), g8 = idx - lr * (C / 8);
     const int row = cu0 - 2 + lr;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
@@ -89,8 +110,8 @@ __global__ __launch_bounds__(512) void resblock_kernel(ResDev p) {
       a = *reinterpret_cast<const float4*>(src);
       c = *reinterpret_cast<const float4*>(src + 4);
     }
-    a = make_float4(elu1(a.x), elu1(a.y), elu1(a.z), elu1(a.w));
-    c = make_float4(elu1(c.x), elu1(c.y), elu1(c.z), elu1(c.w));
+    a = make_float4(elu_fast(a.x), elu_fast(a.y), elu_fast(a.z), elu_fast(a.w));
+    c = make_float4(elu_fast(c.x), elu_fast(c.y), elu_fast(c.z), elu_fast(c.w));
     uint4 h, m, l;
     split3x8(a, c, h, m, l);
     const int slot = ((g8 >> 2) * 4 + (g8 & 3)) * RLP + lr;  // [x chunk][q][row] inside a piece plane
@@ -98,22 +119,22 @@ __global__ __launch_bounds__(512) void resblock_kernel(ResDev p) {
     hp[slot + CC * 4 * RLP] = m;
     hp[slot + 2 * CC * 4 * RLP] = l;
   }
-  stage_w(p.w2, NT2, K2C, 0, K::GK2);
+  ST_STORE_W(NT2, K::GK2)
   __syncthreads();
 
   // ---- phase B: hidden = conv k3 over ELU(x): out row i reads ELU(x) local rows i, i+1, i+2 (taps 0..2)
   {
-    constexpr int RW = MT / WR, CW = NT2 / WC;
+    constexpr int RW = MT / WR, CW = NT2 / WC, G2 = K2C / K::GK2;
     f32x4 acc[RW][CW];
 #pragma unroll
     for (int i = 0; i < RW; ++i)
 #pragma unroll
       for (int j = 0; j < CW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int g = 0; g < K2C / K::GK2; ++g) {
-      if (g > 0) {
-        __syncthreads();
-        stage_w(p.w2, NT2, K2C, g * K::GK2, K::GK2);
-        __syncthreads();
+    for (int g = 0; g < G2; ++g) {
+      if (g + 1 < G2) {  // next group (or conv k1's first chunk) in flight
+        ST_FETCH_W(p.w2, NT2, K2C, (g + 1) * K::GK2, K::GK2)
+      } else {
+        ST_FETCH_W(p.w3, NT3, HC, 0, K::GK3)
       }
 #pragma unroll
       for (int kcl = 0; kcl < K::GK2; ++kcl) {
@@ -133,6 +154,13 @@ __global__ __launch_bounds__(512) void resblock_kernel(ResDev p) {
           }
         }
       }
+      __syncthreads();  // everyone is done with this group
+      if (g + 1 < G2) {
+        ST_STORE_W(NT2, K::GK2)
+        __syncthreads();
+      } else {
+        ST_STORE_W(NT3, K::GK3)
+      }
     }
     // hidden + bias -> ELU -> pieces: the lane holds hidden[row mt*16 + r][n = ct*16 + 4q .. +4)
     uint2* vp2 = reinterpret_cast<uint2*>(vp);
@@ -142,7 +170,8 @@ __global__ __launch_bounds__(512) void resblock_kernel(ResDev p) {
       for (int j = 0; j < CW; ++j) {
         const int row = (wr + i * WR) * 16 + r, ct = wc * CW + j, n = ct * 16 + 4 * q;
         const float4 bb = *reinterpret_cast<const float4*>(p.b2 + n);
-        const float v0 = elu1(acc[i][j][0] + bb.x), v1 = elu1(acc[i][j][1] + bb.y), v2 = elu1(acc[i][j][2] + bb.z), v3 = elu1(acc[i][j][3] + bb.w);
+        const float v0 = elu_fast(acc[i][j][0] + bb.x), v1 = elu_fast(acc[i][j][1] + bb.y), v2 = elu_fast(acc[i][j][2] + bb.z),
+                    v3 = elu_fast(acc[i][j][3] + bb.w);
         uint32_t h0, m0, l0, h1, m1, l1;
         split3_pair(v0, v1, h0, m0, l0);
         split3_pair(v2, v3, h1, m1, l1);
@@ -152,21 +181,28 @@ __global__ __launch_bounds__(512) void resblock_kernel(ResDev p) {
         vp2[s2 + HC * 4 * RC * 2] = make_uint2(m0, m1);
         vp2[s2 + 2 * HC * 4 * RC * 2] = make_uint2(l0, l1);
       }
+    __syncthreads();  // hidden pieces and conv k1's first chunk are in LDS
   }
 
   // ---- phase C: y = conv k1 over ELU(hidden) + x
   const bool stream_start = FINAL && p.slot_pos[b] == 0 && blockIdx.x == 0;
   {
-    constexpr int RW = MT / WR, CW = NT3 / WC;
+    constexpr int RW = MT / WR, CW = NT3 / WC, G3 = HC / K::GK3;
     f32x4 acc[RW][CW];
+    float4 xres[RW][CW];  // the residual: x again (L2), requested before the MFMAs
 #pragma unroll
-    for (int i = 0; i < RW; ++i)
+    for (int i = 0; i < RW; ++i) {
+      const int grow = cu0 + (wr + i * WR) * 16 + r;
 #pragma unroll
-      for (int j = 0; j < CW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int g = 0; g < HC / K::GK3; ++g) {
-      __syncthreads();  // phase B (or the previous group) is done with wb; the hidden pieces are complete
-      stage_w(p.w3, NT3, HC, g * K::GK3, K::GK3);
-      __syncthreads();
+      for (int j = 0; j < CW; ++j) {
+        acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        xres[i][j] = grow < p.T ? *reinterpret_cast<const float4*>(xb + (long)grow * C + (wc * CW + j) * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    for (int g = 0; g < G3; ++g) {
+      if (g + 1 < G3) {
+        ST_FETCH_W(p.w3, NT3, HC, (g + 1) * K::GK3, K::GK3)
+      }
 #pragma unroll
       for (int kcl = 0; kcl < K::GK3; ++kcl) {
         const int kc = g * K::GK3 + kcl;
@@ -185,7 +221,13 @@ __global__ __launch_bounds__(512) void resblock_kernel(ResDev p) {
           }
         }
       }
+      if (g + 1 < G3) {
+        __syncthreads();
+        ST_STORE_W(NT3, K::GK3)
+        __syncthreads();
+      }
     }
+    if (FINAL) __syncthreads();  // ELU(y) overwrites the ELU(x) pieces and nothing may still be reading LDS operands of this phase
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
       const int row = (wr + i * WR) * 16 + r, grow = cu0 + row;
@@ -194,10 +236,9 @@ __global__ __launch_bounds__(512) void resblock_kernel(ResDev p) {
         const int n = (wc * CW + j) * 16 + 4 * q;
         float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
         if (grow < p.T) {
-          const float4 xr = *reinterpret_cast<const float4*>(xb + (long)grow * C + n);  // the residual: x again (L2)
-          const float4 bb = *reinterpret_cast<const float4*>(p.b3 + n);
-          e = make_float4(elu1(acc[i][j][0] + bb.x + xr.x), elu1(acc[i][j][1] + bb.y + xr.y), elu1(acc[i][j][2] + bb.z + xr.z),
-                          elu1(acc[i][j][3] + bb.w + xr.w));
+          const float4 bb = *reinterpret_cast<const float4*>(p.b3 + n), xr = xres[i][j];
+          e = make_float4(elu_fast(acc[i][j][0] + bb.x + xr.x), elu_fast(acc[i][j][1] + bb.y + xr.y), elu_fast(acc[i][j][2] + bb.z + xr.z),
+                          elu_fast(acc[i][j][3] + bb.w + xr.w));
         }
         if (FINAL) {
           if (stream_start && grow < 0) e = make_float4(0.f, 0.f, 0.f, 0.f);  // before the stream: the output conv's zero padding
@@ -208,6 +249,9 @@ __global__ __launch_bounds__(512) void resblock_kernel(ResDev p) {
       }
     }
   }
+
+#undef ST_FETCH_W
+#undef ST_STORE_W
 
   // ---- phase D (last stage): PCM sample u0 + i = bf + sum_{tap, c} wf[tap][c] * ELU(y)[i + tap][c]; 4 threads per sample
   if (FINAL) {
@@ -233,17 +277,17 @@ __global__ __launch_bounds__(512) void resblock_kernel(ResDev p) {
   }
 }
 
-template <int C, int RC, bool FINAL>
+template <int C, int RC, bool FINAL, int NW>
 int launch_res(const ResDev& d, int batch, hipStream_t st) {
-  using K = ResCfg<C, RC, FINAL>;
+  using K = ResCfg<C, RC, FINAL, NW>;
   static bool attr_set = false;
   if (!attr_set) {  // > 64 KB of dynamic LDS must be requested once per kernel
-    ST_CHECK_HIP(hipFuncSetAttribute((const void*)resblock_kernel<C, RC, FINAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS));
+    ST_CHECK_HIP(hipFuncSetAttribute((const void*)resblock_kernel<C, RC, FINAL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS));
     attr_set = true;
   }
   const dim3 grid((d.T + K::RT - 1) / K::RT, batch);
   ST_REQUIRE(grid.y <= 65535, SMOLTTS_E_INVALID, "resblock: batch too large");
-  hipLaunchKernelGGL((resblock_kernel<C, RC, FINAL>), grid, dim3(512), K::LDS, st, d);
+  hipLaunchKernelGGL((resblock_kernel<C, RC, FINAL, NW>), grid, dim3(NW * 64), K::LDS, st, d);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
 }
@@ -256,11 +300,11 @@ int launch_seanet_resblock(const MimiResblockArgs& a, hipStream_t st) {
            a.final_w, a.final_b, a.pcm, (long)a.pcm_stride, a.slot_pos};
   if (a.channels == 128 && !a.final_conv) {
     ST_REQUIRE(a.out, SMOLTTS_E_INVALID, "resblock: null output");
-    return launch_res<128, 64, false>(d, a.batch, st);
+    return launch_res<128, 32, false, 8>(d, a.batch, st);
   }
   if (a.channels == 64 && a.final_conv) {
     ST_REQUIRE(a.final_w && a.pcm && a.slot_pos, SMOLTTS_E_INVALID, "resblock: the last stage needs the output conv, pcm and slot positions");
-    return launch_res<64, 128, true>(d, a.batch, st);
+    return launch_res<64, 32, true, 4>(d, a.batch, st);
   }
   set_error("resblock: no instance for %d channels, final_conv=%d", a.channels, a.final_conv);
   return SMOLTTS_E_INVALID;

@@ -1,0 +1,28 @@
+"""Time of one Mimi chunk decode (default 32 slots x 32 frames = 1024 frames), HIP events, best of 5.  argv: [slots] [frames]."""
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch  # noqa: E402
+
+from smoltts_amd.codec.synthetic import synthetic_mimi_state  # noqa: E402
+from smoltts_amd.engine import MimiEngine, MimiSession  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+eng = MimiEngine(synthetic_mimi_state(seed=0), 8, window=0, max_positions=2 * F * 8 + 16)
+sess = MimiSession(eng, max_batch=B, max_chunk_frames=F)
+codes = torch.randint(0, 2048, (B, F * 8, 8), dtype=torch.int32, device="cuda")
+pcm = torch.zeros(B, F * 8 * 1920, device="cuda")
+best = 1e9
+for rep in range(3):
+    sess.reset()
+    for i in range(7):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        sess.decode_chunk(codes, i * F, F, pcm, code_offset=0)
+        b.record()
+        torch.cuda.synchronize()
+        if i:
+            best = min(best, a.elapsed_time(b))
+print(f"Mimi chunk decode {B} slots x {F} frames: {best:.3f} ms ({best * 1e3 / (B * F):.2f} us per frame)")
