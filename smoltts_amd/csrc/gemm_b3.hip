@@ -138,6 +138,9 @@ static int launch_b3_epi(const GemmDev& d, hipStream_t stream) {
 
 bool gemm_b3_applies(int M, int N, int K, int epilogue) {
   if (M < 256 || N < 64 || N % 4 != 0 || K % 32 != 0) return false;
+  // no split-K here: with fewer than ~3/4 of the CUs busy (streaming passes of a few frames) the K-split skinny kernel of
+  // gemm.hip has the shorter critical path
+  if ((long)((M + 63) / 64) * ((N + 63) / 64) < 192) return false;
   return epilogue == SMOLTTS_EPI_STORE || epilogue == SMOLTTS_EPI_RESID || epilogue == SMOLTTS_EPI_GELU ||
          epilogue == SMOLTTS_EPI_SCALE_RESID || epilogue == SMOLTTS_EPI_QKV_ROPE;
 }

@@ -40,6 +40,9 @@ class _Request:
     pending: list = field(default_factory=list)  # blocking requests: audio-code columns awaiting their codec pass
     prompt: object = None
     first_tick: int = 0  # index of the tick that produces this request's frame 0: older snapshots show the slot's previous tenant
+    last_tick: int = 1 << 62  # index of the tick in which the frame budget runs out (known at admission): the slot's next tenant may
+                              # be queued right behind it, before the host has seen that tick's snapshot
+    retired: bool = False     # the slot has been handed to the next tenant; later snapshots of the slot are not this request's
     cancelled: bool = False  # set by the client side (cancel / an abandoned chunk iterator), honoured by the worker at its next look
     closed: bool = False  # the end marker (None or an exception) has been queued
 
@@ -74,6 +77,8 @@ class BatchScheduler:
         self._torch = torch
         self._pending: "queue.Queue[_Request]" = queue.Queue()
         self._active: Dict[int, _Request] = {}
+        self._retiring: List[_Request] = []     # budget-terminated requests whose slot already has its next tenant; their last
+                                                # snapshots are still to be read
         self._free: List[int] = list(range(max_batch))
         self._stop = threading.Event()
         self._wake = threading.Event()          # set by submit(): the idle worker sleeps on it (no peeking into the queue)
@@ -143,7 +148,7 @@ class BatchScheduler:
             self._draining = True
             deadline = time.time() + timeout
             while (self._thread.is_alive() and time.time() < deadline and
-                   (self._active or self._held is not None or not self._pending.empty() or self._codec_backlog() or self._deliveries)):
+                   (self._active or self._retiring or self._held is not None or not self._pending.empty() or self._codec_backlog() or self._deliveries)):
                 time.sleep(0.01)
         self._stop.set()
         self._wake.set()
@@ -158,6 +163,16 @@ class BatchScheduler:
     def _admit(self) -> None:
         new: List[_Request] = []
         rows = 0  # prompt rows of the (first) prefill call of this admission; the session's workspace holds max_rows
+        if self._held is not None or not self._pending.empty():
+            # A request that ends by its frame budget ends in a tick known since its admission.  Once that tick is queued the
+            # slot can take its next tenant straight away: the prefill is queued behind the tick, and the snapshots (device-side
+            # copies queued behind their ticks) still show the old tenant's last frames when the host gets to them.
+            for slot, r in list(self._active.items()):
+                if r.last_tick < self._tick_no and not r.cancelled:
+                    r.retired = True
+                    self._retiring.append(r)
+                    del self._active[slot]
+                    self._free.append(slot)
         while self._free and (self._held is not None or not self._pending.empty()):
             req, self._held = (self._held, None) if self._held is not None else (self._pending.get_nowait(), None)
             if req.cancelled:
@@ -200,6 +215,7 @@ class BatchScheduler:
                 self._codec_age[b] = 0
         for r in new:
             r.first_tick = self._tick_no
+            r.last_tick = self._tick_no + -(-(r.max_new_tokens + 1) // self.tick) - 1  # ceil(frames / tick) ticks from first_tick on
             self._active[r.slot] = r
 
     def _prefill(self, new: List[_Request]) -> None:
@@ -285,14 +301,26 @@ class BatchScheduler:
     def _drain(self, codes, n_frames, done, tick_no: int, pcm) -> None:
         nq = self.tts.config.num_codebooks
         tc = self.tts.token_config
-        for slot, r in list(self._active.items()):
+
+        def release(r):  # the request needs its slot no longer (a retired one has handed it over already)
+            if r.retired:
+                self._retiring.remove(r)
+            else:
+                del self._active[r.slot]
+                self._free.append(r.slot)
+
+        for r in self._retiring + list(self._active.values()):
+            slot = r.slot
             if r.cancelled:  # the client is gone: free the slot now, whatever the snapshot shows
-                del self._active[slot]
-                self._free.append(slot)
+                release(r)
                 r.pending = []
                 self._end(r)
                 continue
             if tick_no < r.first_tick:  # the snapshot predates this request: it shows the slot's previous tenant
+                continue
+            if r.retired and tick_no > r.last_tick:  # (cannot happen: a retired request ends with its last tick's snapshot)
+                release(r)
+                self._end(r, RuntimeError("scheduler lost the last frames of a request"))
                 continue
             n = min(int(n_frames[slot]), r.max_new_tokens + 1)
             finished = (bool(done[slot]) and int(n_frames[slot]) > 0) or n >= r.max_new_tokens + 1
@@ -306,8 +334,7 @@ class BatchScheduler:
                     self._counts["frames_delivered"] += k
                 r.emitted = n
                 if finished:
-                    del self._active[slot]
-                    self._free.append(slot)
+                    release(r)
                     self._end(r)
                 continue
             # blocking requests keep only frames whose slow id is a semantic token (generate_blocking, lm/generate.py:196-207)
@@ -318,8 +345,7 @@ class BatchScheduler:
             if cols.shape[0]:
                 r.pending.append(cols)
             if finished:
-                del self._active[slot]
-                self._free.append(slot)
+                release(r)
                 self._finished.append(r)
 
     # ------------------------------------------------------------------ worker: codec passes and delivery
@@ -472,13 +498,14 @@ class BatchScheduler:
         if self._held is not None:
             self._end(self._held, e)
             self._held = None
-        for r in list(self._active.values()) + self._finished + [j.req for j in self._codec_jobs if j is not None]:
+        for r in list(self._active.values()) + self._retiring + self._finished + [j.req for j in self._codec_jobs if j is not None]:
             self._end(r, e)
         self._codec_jobs = [None] * len(self._codec_jobs)
         for _, _, items in self._deliveries:
             for r, _, _, _ in items:
                 self._end(r, e)
         self._active.clear()
+        self._retiring = []
         self._finished = []
         self._deliveries = []
         while not self._pending.empty():
