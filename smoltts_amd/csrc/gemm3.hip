@@ -203,6 +203,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
     }
   }
 
+  STAMP3(5);  // every load of the kernel has been issued
   for (int c0 = wave; c0 < nchunks;) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
