@@ -41,7 +41,14 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmDev p) {
   const int r = lane & 15, q = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
   const int nchunks = p.K >> 5;
-  const int row0 = blockIdx.y * BM, tile0 = blockIdx.x * NT;
+  // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (id % 8), each with its own L2.  The column
+  // blocks of one row block all read the same X rows: they get consecutive slots on ONE XCD (row blocks are dealt over the
+  // XCDs instead), so X leaves HBM / the Infinity Cache once, not once per column block (rocprofv3 FETCH_SIZE of the
+  // 256 -> 128 ConvTranspose, 5 column blocks: 1.15 GB per 1024 frames with the plain 2-D grid against 0.1 GB of X).
+  const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+  const int cb = kk % p.grid_cb, rb = (kk / p.grid_cb) * 8 + xcd;
+  if (rb >= p.grid_rb) return;  // the grid is padded to whole groups of 8 row blocks (uniform over the workgroup)
+  const int row0 = rb * BM, tile0 = cb * NT;
 
   const float* xsrc[XI];
   int xdst[XI];
@@ -124,13 +131,22 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmDev p) {
 template <int EPI>
 static int launch_b3_epi(const GemmDev& d, hipStream_t stream) {
   auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
-  ST_REQUIRE((d.M + 63) / 64 <= 65535, SMOLTTS_E_INVALID, "gemm_b3: M=%d too large for one launch", d.M);
+  GemmDev g = d;
+  auto grid1d = [&](int bm, int bn) {  // 8 consecutive ids = 8 XCDs = 8 different row blocks, see the kernel
+    g.grid_rb = (d.M + bm - 1) / bm;
+    g.grid_cb = (d.N + bn - 1) / bn;
+    return dim3((unsigned)(((g.grid_rb + 7) / 8) * 8 * g.grid_cb));
+  };
+  ST_REQUIRE(blocks(64, 64) < (1L << 30), SMOLTTS_E_INVALID, "gemm_b3: M=%d too large for one launch", d.M);
   if (blocks(128, 128) >= 256 && d.N >= 128) {
-    hipLaunchKernelGGL((gemm_b3_kernel<4, 4, EPI>), dim3((d.N + 127) / 128, (d.M + 127) / 128), dim3(256), 0, stream, d);
+    const dim3 grid = grid1d(128, 128);
+    hipLaunchKernelGGL((gemm_b3_kernel<4, 4, EPI>), grid, dim3(256), 0, stream, g);
   } else if (blocks(128, 64) >= 256) {
-    hipLaunchKernelGGL((gemm_b3_kernel<4, 2, EPI>), dim3((d.N + 63) / 64, (d.M + 127) / 128), dim3(256), 0, stream, d);
+    const dim3 grid = grid1d(128, 64);
+    hipLaunchKernelGGL((gemm_b3_kernel<4, 2, EPI>), grid, dim3(256), 0, stream, g);
   } else {
-    hipLaunchKernelGGL((gemm_b3_kernel<2, 2, EPI>), dim3((d.N + 63) / 64, (d.M + 63) / 64), dim3(256), 0, stream, d);
+    const dim3 grid = grid1d(64, 64);
+    hipLaunchKernelGGL((gemm_b3_kernel<2, 2, EPI>), grid, dim3(256), 0, stream, g);
   }
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;

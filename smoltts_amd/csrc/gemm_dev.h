@@ -29,6 +29,7 @@ struct GemmDev {
   float* vc;
   int n_q_heads, n_kv_heads, cache_len;
   unsigned long long* stamps;  // diagnostic build aid (SMOLTTS debug API); nullptr in production
+  int grid_rb, grid_cb;        // gemm_b3: row blocks x column blocks of the (1-D, XCD-aware) launch
 };
 
 __device__ __forceinline__ long row_off(int m, int rpb, long ld, long bstride) {
