@@ -43,6 +43,7 @@ class _Request:
     last_tick: int = 1 << 62  # index of the tick in which the frame budget runs out (known at admission): the slot's next tenant may
                               # be queued right behind it, before the host has seen that tick's snapshot
     retired: bool = False     # the slot has been handed to the next tenant; later snapshots of the slot are not this request's
+    stream_done: bool = False  # streaming: the last frames have been seen (the end marker goes out with the last codec pass)
     cancelled: bool = False  # set by the client side (cancel / an abandoned chunk iterator), honoured by the worker at its next look
     closed: bool = False  # the end marker (None or an exception) has been queued
 
@@ -58,7 +59,7 @@ class BatchScheduler:
     CODEC_BATCH, CODEC_CHUNK, CODEC_WAIT = 16, 64, 32  # slots, frames per slot and pass, LM frames a pass may wait for company
 
     def __init__(self, tts, max_batch: int = 32, frames_per_tick: int = 4, generation_settings=None, max_prompt_rows: int = 4096,
-                 prefill_chunk: Optional[int] = 128):
+                 prefill_chunk: Optional[int] = 128, overlap_stream_codec: bool = True):
         import torch
 
         from ..config import GenerationSettings
@@ -69,6 +70,9 @@ class BatchScheduler:
         self.B = max_batch
         self.tick = frames_per_tick
         self.prefill_chunk = prefill_chunk  # columns per utterance per prefill call (None: whole prompts at once)
+        # streaming requests: the codec pass of tick k is launched on a second stream by the host once it has seen tick k finish
+        # (it waits for that anyway, to read the tick's snapshot), i.e. while tick k+1 runs -- instead of in line between the ticks
+        self.overlap_stream_codec = overlap_stream_codec
         self.settings = generation_settings or GenerationSettings.greedy()
         self.max_frames = self.settings.max_new_tokens + 1
         self.session = LMSession(tts.lm, max_batch, max_seq=tts.config.max_seq_len, max_rows=max(max_prompt_rows, max_batch),
@@ -210,9 +214,10 @@ class BatchScheduler:
             if self._stream_codec is None:
                 self._stream_codec = MimiSession(self.tts.codec, max_batch=self.B, max_chunk_frames=max(self.tick, 1))
                 self._stream_codec.reset()
-            self._stream_codec.reset_slots(streams)
-            for b in streams:
-                self._codec_age[b] = 0
+            if not self.overlap_stream_codec:  # (overlapped: the slot's stream restarts on the codec stream, right before the pass
+                self._stream_codec.reset_slots(streams)  # of the request's first tick and behind the previous tenant's last pass)
+                for b in streams:
+                    self._codec_age[b] = 0
         for r in new:
             r.first_tick = self._tick_no
             r.last_tick = self._tick_no + -(-(r.max_new_tokens + 1) // self.tick) - 1  # ceil(frames / tick) ticks from first_tick on
@@ -240,7 +245,7 @@ class BatchScheduler:
         self.session.decode(self.tick)
         s = self.session
         pcm = None
-        streaming = [r for r in self._active.values() if r.stream]
+        streaming = [] if self.overlap_stream_codec else [r for r in self._active.values() if r.stream]
         if streaming:
             # the frames this tick gives slot b sit at ring positions [f0_b, f0_b + tick): f0_b follows from the tick count
             # alone while the request is alive (frames of a slot that has stopped are garbage here and never delivered)
@@ -280,13 +285,49 @@ class BatchScheduler:
             # the host waits for the snapshot, then copies on the copy stream: a device-side wait would park a blocked barrier
             # packet in a second hardware queue for the whole tick, and the frame graphs' dependent launches get slower for it
             self._wait_event(ev)
+            stream_pass = self._launch_stream_codec(codes_d, tick_no) if self.overlap_stream_codec else None
             with torch.cuda.stream(self._copy_stream):
                 codes = codes_d.to("cpu", non_blocking=True)
                 n_frames = n_d.to("cpu", non_blocking=True)
                 done = done_d.to("cpu", non_blocking=True)
                 pcm = pcm_d.to("cpu", non_blocking=True) if pcm_d is not None else None
             self._sync_copies()
-            self._drain(codes.numpy(), n_frames.numpy(), done.numpy(), tick_no, None if pcm is None else pcm.numpy())
+            self._drain(codes.numpy(), n_frames.numpy(), done.numpy(), tick_no, None if pcm is None else pcm.numpy(), stream_pass)
+
+    def _launch_stream_codec(self, codes_d, tick_no: int):
+        """The codec pass of the streaming requests for tick ``tick_no``, on the codec stream, from the tick's snapshot of the
+        output ring (the host has just seen that snapshot's event, so the next tick is running meanwhile).  Returns
+        (pcm on the device, event) or None when no stream was alive in that tick."""
+        torch = self._torch
+        alive = [r for r in self._retiring + list(self._active.values())
+                 if r.stream and r.first_tick <= tick_no <= r.last_tick and not r.closed and not r.stream_done]
+        if not alive or self._stream_codec is None:
+            return None
+        from ..engine import upload
+
+        with torch.cuda.stream(self._codec_stream):
+            live = {r.slot for r in alive}
+            cap = int(self.tts.codec.c_cfg.max_positions)
+            restart = [r.slot for r in alive if r.first_tick == tick_no]  # new streams start at position 0 ...
+            restart += [b for b in range(self.B) if b not in live and (self._codec_age[b] + 2) * 2 * self.tick > cap]  # ... idle slots before they overflow
+            if restart:
+                self._stream_codec.reset_slots(sorted(set(restart)))
+                for b in restart:
+                    self._codec_age[b] = 0
+            for b in range(self.B):
+                self._codec_age[b] += 1
+            f0 = np.zeros(self.B, np.int64)
+            for r in alive:
+                f0[r.slot] = (tick_no - r.first_tick) * self.tick
+            f0_d, = upload([f0], self.session.engine.device)
+            idx = (f0_d[:, None] + torch.arange(self.tick, device="cuda")[None]).clamp_(max=self.max_frames - 1)
+            nq = self.tts.config.num_codebooks
+            chunk = codes_d[torch.arange(self.B, device="cuda")[:, None], idx][:, :, -nq:].contiguous()
+            pcm = torch.empty(self.B, self.tick * 1920, dtype=torch.float32, device="cuda")
+            self._stream_codec.decode_chunk(chunk, 0, self.tick, pcm, code_offset=0)
+            ev = torch.cuda.Event()
+            ev.record(self._codec_stream)
+        return pcm, ev, codes_d  # (codes_d: kept alive until the pass has run)
 
     def _wait_event(self, ev) -> None:
         t = time.perf_counter()
@@ -298,7 +339,8 @@ class BatchScheduler:
         self._copy_stream.synchronize()
         self._gpu_wait_s += time.perf_counter() - t
 
-    def _drain(self, codes, n_frames, done, tick_no: int, pcm) -> None:
+    def _drain(self, codes, n_frames, done, tick_no: int, pcm, stream_pass=None) -> None:
+        stream_items = []  # overlapped codec pass of this tick: (request, pcm row, samples, last?) handed out by _deliver
         nq = self.tts.config.num_codebooks
         tc = self.tts.token_config
 
@@ -328,6 +370,15 @@ class BatchScheduler:
                 # streaming requests decode every frame (__init__.py:88-92); this tick's PCM of the slot starts at its frame
                 # r.emitted (== f0 of the tick: one codec frame per LM frame)
                 k = n - r.emitted
+                if self.overlap_stream_codec:
+                    if k > 0 or finished:
+                        assert k == 0 or (stream_pass is not None and r.emitted == (tick_no - r.first_tick) * self.tick), "stream bookkeeping out of step"
+                        stream_items.append((r, slot, max(k, 0) * 1920, finished, r.emitted == 0))
+                    r.emitted = n
+                    if finished:
+                        r.stream_done = True
+                        release(r)  # the end marker follows the last chunk, in _deliver
+                    continue
                 if k > 0:
                     assert pcm is not None and r.emitted == (tick_no - r.first_tick) * self.tick, "stream bookkeeping out of step"
                     r.out.put(pcm[slot, : k * 1920].copy())
@@ -347,6 +398,10 @@ class BatchScheduler:
             if finished:
                 release(r)
                 self._finished.append(r)
+        if stream_items:
+            pcm_d, ev, keep = stream_pass if stream_pass is not None else (None, None, None)
+            urgent = any(it[4] for it in stream_items)  # a first chunk: handed out as soon as the pass is through
+            self._deliveries.append((ev, pcm_d, [it[:4] for it in stream_items], urgent, keep))
 
     # ------------------------------------------------------------------ worker: codec passes and delivery
     def _codec_backlog(self) -> bool:
@@ -376,7 +431,7 @@ class BatchScheduler:
             cols = np.concatenate(r.pending) if r.pending else np.zeros((0, nq), np.int32)
             r.pending = []
             if cols.shape[0] == 0:  # nothing to decode (every frame was non-semantic): just close the response, in order
-                self._deliveries.append((None, None, [(r, 0, 0, True)]))
+                self._deliveries.append((None, None, [(r, 0, 0, True)], False, None))
                 continue
             b = jobs.index(None)
             jobs[b] = _CodecJob(r, cols)
@@ -390,6 +445,16 @@ class BatchScheduler:
         if not (force or len(occupied) == len(jobs) or self._codec_wait >= (max(1, self.CODEC_WAIT // self.tick) if busy else 1)):
             return
         self._codec_wait = 0
+        # these passes depend on nothing the frame graphs produce on the device (their codes come from the host): they run on
+        # the codec stream, beside the ticks
+        side = self._codec_stream if self.overlap_stream_codec else torch.cuda.current_stream()
+        with torch.cuda.stream(side):
+            self._decode_finished_pass(jobs, occupied, nq)
+
+    def _decode_finished_pass(self, jobs, occupied, nq) -> None:
+        from ..engine import MimiSession, upload
+
+        torch = self._torch
         if self._batch_codec is None:
             self._batch_codec = MimiSession(self.tts.codec, max_batch=self.CODEC_BATCH, max_chunk_frames=self.CODEC_CHUNK)
             self._batch_codec.reset()
@@ -425,13 +490,14 @@ class BatchScheduler:
             items.append((j.req, b, n[b] * 1920, fin))
             if fin:
                 jobs[b] = None
-        self._deliveries.append((ev, pcm, items))
+        self._deliveries.append((ev, pcm, items, False, None))
 
     def _deliver(self, wait: bool) -> None:
         """Hand finished codec passes to their requests, in order; ``wait``: block on the oldest one."""
         torch = self._torch
         while self._deliveries:
-            ev, pcm, items = self._deliveries[0]
+            ev, pcm, items, _, _ = self._deliveries[0]
+            wait = wait or any(d[3] for d in self._deliveries)  # a stream's first chunk is somewhere in the line: do not dawdle
             if ev is not None:
                 if not (wait or ev.query()):
                     return
@@ -455,6 +521,7 @@ class BatchScheduler:
         try:
             compute = torch.cuda.Stream()
             self._copy_stream = torch.cuda.Stream()
+            self._codec_stream = torch.cuda.Stream()
             with torch.cuda.stream(compute):
                 while not self._stop.is_set():
                     self._admit()
@@ -501,8 +568,8 @@ class BatchScheduler:
         for r in list(self._active.values()) + self._retiring + self._finished + [j.req for j in self._codec_jobs if j is not None]:
             self._end(r, e)
         self._codec_jobs = [None] * len(self._codec_jobs)
-        for _, _, items in self._deliveries:
-            for r, _, _, _ in items:
+        for d in self._deliveries:
+            for r, _, _, _ in d[2]:
                 self._end(r, e)
         self._active.clear()
         self._retiring = []
