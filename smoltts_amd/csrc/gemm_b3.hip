@@ -15,6 +15,8 @@
 // workgroup.  Per 32-k chunk the workgroup stages its X rows (split into pieces, B-fragment order) and its W3 tiles
 // (already in A-fragment order) in LDS once; every wave reads TM + TN fragments triples and issues 6 TM TN MFMAs;
 // the next chunk's global loads fly under them (register prefetch, one LDS buffer, two barriers per chunk).
+#include <stdlib.h>
+
 #include "gemm_dev.h"
 
 namespace smoltts {
@@ -127,7 +129,10 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmDev p) {
   }
 }
 
-// 128 x 128 tiles when that still gives every CU work, else 128 x 64, else 64 x 64
+// Tile choice, measured on the 16 GEMM shapes of a 1024-frame chunk (tools/microbench_b3.py with SMOLTTS_B3_TILE forced):
+// 128 x 128 tiles win once they make >= 2 workgroups per CU (ConvTranspose stages); below that the 64 x 64 tiles win although
+// they re-read more -- at M = 2048 (conv0, the transformer Linears) what counts is workgroups in flight per CU (5 fit), e.g.
+// conv0 188 -> 137 us, qkv 41 -> 34 us, fc1 48 -> 40 us; 128 x 64 only serves the narrow outputs (N < 128) of long tensors.
 template <int EPI>
 static int launch_b3_epi(const GemmDev& d, hipStream_t stream) {
   auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
@@ -138,10 +143,11 @@ static int launch_b3_epi(const GemmDev& d, hipStream_t stream) {
     return dim3((unsigned)(((g.grid_rb + 7) / 8) * 8 * g.grid_cb));
   };
   ST_REQUIRE(blocks(64, 64) < (1L << 30), SMOLTTS_E_INVALID, "gemm_b3: M=%d too large for one launch", d.M);
-  if (blocks(128, 128) >= 256 && d.N >= 128) {
+  static const int force = [] { const char* e = getenv("SMOLTTS_B3_TILE"); return e ? atoi(e) : 0; }();  // experiments: 44 | 42 | 22
+  if (force == 44 || (force == 0 && blocks(128, 128) >= 512 && d.N >= 128)) {
     const dim3 grid = grid1d(128, 128);
     hipLaunchKernelGGL((gemm_b3_kernel<4, 4, EPI>), grid, dim3(256), 0, stream, g);
-  } else if (blocks(128, 64) >= 256) {
+  } else if (force == 42 || (force == 0 && blocks(128, 64) >= 512 && d.N < 128)) {
     const dim3 grid = grid1d(128, 64);
     hipLaunchKernelGGL((gemm_b3_kernel<4, 2, EPI>), grid, dim3(256), 0, stream, g);
   } else {
