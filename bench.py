@@ -627,15 +627,15 @@ def run_rank(args) -> None:
             _ = buf1.cpu()
         b1_stream_fps = 128 / (time.perf_counter() - t1)
         ms1.close(); ls1.close()
-        first_chunk = {"b1_70m_stream_frames_per_s": round(b1_stream_fps, 1),
-                       "b32_150m_ms_p50": round(float(np.median(t150)), 2),
-                       "b32_150m_steady_ms_p50": round(float(np.median(t150s)), 2), "b32_150m_steady_ms_p95": round(float(np.percentile(t150s, 95)), 2),
+        first_chunk = {"b1_70m_stream_frames_per_s": round(b1_stream_fps, 1), "batch": B, "model": args.model,
+                       "batch_at_once_ms_p50": round(float(np.median(t150)), 2),
+                       "steady_one_arrival_ms_p50": round(float(np.median(t150s)), 2), "steady_one_arrival_ms_p95": round(float(np.percentile(t150s, 95)), 2),
                        "b1_70m_ms_p50": round(float(np.median(t70l)), 2), "b1_70m_ms_p95": round(float(np.percentile(t70l, 95)), 2),
                        "b1_70m_prompts": len(t70l), "prefill_chunk": pch or None,
-                       "includes": f"prefill + frame 0 + Mimi step + D2H copy of 1920 samples; b32_150m: all {B} prompts of this run's model submitted together; "
-                                   f"b32_150m_steady: one new prompt into a session whose {B} slots are all speaking"
+                       "includes": f"prefill + frame 0 + Mimi step + D2H copy of 1920 samples; batch_at_once: all {B} prompts of this run's model submitted together; "
+                                   f"steady_one_arrival: one new prompt into a session whose {B} slots are all speaking"
                                    + (f"; prompts enter in chunks of {pch} columns (chunked prefill inside the timed figure)" if pch else "")}
-        log(f"first audio chunk: B={B} {args.model} p50 {first_chunk['b32_150m_ms_p50']} ms (all at once) / {first_chunk['b32_150m_steady_ms_p50']} ms "
+        log(f"first audio chunk: B={B} {args.model} p50 {first_chunk['batch_at_once_ms_p50']} ms (all at once) / {first_chunk['steady_one_arrival_ms_p50']} ms "
             f"(one arrival among {B} speaking slots); B=1 70m p50 {first_chunk['b1_70m_ms_p50']} ms")
 
     if rank == 0:

@@ -32,6 +32,8 @@ constexpr int BUF_C[NBUF] = {512, 1024, 512, 256, 512, 256, 128, 256, 128, 64, 1
 // output conv applied in the same kernel); buffers 9, 12, 13 are unused.
 constexpr int BUF_HALO[NBUF] = {6, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 4, 0, 2};
 constexpr bool FUSED_BLOCK[NCONV] = {false, false, false, false, false, false, false, false, true, false, false, true, false, false};
+// a fused block's inner tensors (the hidden; for the last stage also the block output) never exist in HBM
+constexpr bool buf_used(int i) { return !((i >= 1 && FUSED_BLOCK[i - 1]) || (i == NBUF - 1 && FUSED_BLOCK[NBUF - 3])); }
 constexpr int BUF_RPF[NBUF] = {2, 2, 16, 16, 16, 96, 96, 96, 480, 480, 480, 1920, 1920, 1920};
 // buffer index feeding each conv (conv c reads BUF[c]; writes BUF[c+1], the last writes pcm)
 }  // namespace
@@ -89,14 +91,14 @@ void carve(SmolttsMimiSession* s, char* base, size_t* total) {
   s->carry[1] = cv.take<float>(B * D);
   s->pos_dev = cv.take<int>(B);
   for (int i = 0; i < NBUF; ++i) {
-    s->buf_bstride[i] = (size_t)(BUF_HALO[i] + BUF_RPF[i] * F) * BUF_C[i];
+    s->buf_bstride[i] = buf_used(i) ? (size_t)(BUF_HALO[i] + BUF_RPF[i] * F) * BUF_C[i] : 0;
     s->buf[i] = cv.take<float>(B * s->buf_bstride[i]);
   }
   s->zero_begin = base ? base + z0 : nullptr;
   s->zero_bytes = cv.off - z0;
-  for (int j = 0; j < 4; ++j) {  // raw copies of buffers 2, 5, 8, 11 (no halo: only read row-aligned)
+  for (int j = 0; j < 4; ++j) {  // raw copies of buffers 2, 5 (8, 11: the fused blocks read the raw tensor itself); no halo
     const int i = 2 + 3 * j;
-    s->raw_bstride[j] = (size_t)BUF_RPF[i] * F * BUF_C[i];
+    s->raw_bstride[j] = FUSED_BLOCK[i] ? 0 : (size_t)BUF_RPF[i] * F * BUF_C[i];
     s->raw[j] = cv.take<float>(B * s->raw_bstride[j]);
   }
   // --- scratch / caches (need no zeroing: only positions < `positions` are ever read)
@@ -317,7 +319,7 @@ int smoltts_mimi_reset_slots(SmolttsMimiSession* s, const int32_t* slots_host, i
     ST_CHECK_HIP(hipMemsetAsync(s->carry[1] + (size_t)b * D, 0, D * sizeof(float), st));
     ST_CHECK_HIP(hipMemsetAsync(s->pos_dev + b, 0, sizeof(int), st));
     for (int j = 0; j < NBUF; ++j)  // only the halo rows carry state from chunk to chunk
-      if (BUF_HALO[j] > 0)
+      if (BUF_HALO[j] > 0 && buf_used(j))
         ST_CHECK_HIP(hipMemsetAsync(s->buf[j] + (size_t)b * s->buf_bstride[j], 0, (size_t)BUF_HALO[j] * BUF_C[j] * sizeof(float), st));
     s->pos_host[b] = 0;
   }
@@ -439,7 +441,7 @@ static int decode_chunk_impl(SmolttsMimiSession* s, const int32_t* codes_dev, in
     HaloDesc d;
     for (int i = 0; i < NBUF; ++i) {
       d.buf[i] = s->buf[i]; d.bstride[i] = (long)s->buf_bstride[i];
-      d.C[i] = BUF_C[i]; d.halo[i] = BUF_HALO[i]; d.T[i] = BUF_RPF[i] * F;
+      d.C[i] = BUF_C[i]; d.halo[i] = buf_used(i) ? BUF_HALO[i] : 0; d.T[i] = BUF_RPF[i] * F;
     }
     hipLaunchKernelGGL(halo_shift_kernel, dim3(batch, NBUF), dim3(256), 6 * 512 * sizeof(float), st, d);
     ST_CHECK_HIP(hipGetLastError());
