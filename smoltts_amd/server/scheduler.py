@@ -540,7 +540,15 @@ class BatchScheduler:
                     # ... while the host looks at what tick k-1 produced; unless a stream is still waiting for its first
                     # chunk: then this tick is read as soon as it is done (first-audio latency before pipelining)
                     first_chunk_due = any(r.stream and r.emitted == 0 for r in self._active.values())
-                    self._consume_snapshots(keep=0 if first_chunk_due else 1)
+                    if self.overlap_stream_codec:
+                        # the codec pass of tick k-1 goes out now, beside tick k; reading tick k itself right away (keep=0) would
+                        # leave the GPU idle until the next tick is queued -- with an arrival every other tick that was ~10 % of
+                        # the wall time -- and would not bring the first chunk any earlier: it needs tick k finished either way
+                        self._consume_snapshots(keep=1)
+                        if any(d[3] for d in self._deliveries):
+                            self._deliver(wait=False)  # a first chunk: wait for its pass (the running tick leaves the host slack)
+                    else:
+                        self._consume_snapshots(keep=0 if first_chunk_due else 1)
             self._fail_all(RuntimeError("scheduler closed"))  # requests still in flight when close() was called
         except Exception as e:  # engine failure: fail every waiter loudly
             self._fail_all(e)

@@ -1,7 +1,8 @@
-"""Decode-only harness for the rocprofv3 --pmc passes (tools/collect_pmc.sh): smoltts_byte_150m, B=32 slots,
-64 frame-graph replays (synchronised every 3 frames: the counter service deadlocks behind a long queue of graph launches).  The prompts are prefilled 8 slots at a time (< 256 rows per call) because rocprofv3's
-counter service crashes / hangs on bench.py's 3539-row prefill launches; the decode kernels and their shapes are
-exactly those of `python bench.py` (the w1|w3 GEMM does not depend on the context length)."""
+"""Round 1's decode-only harness for the rocprofv3 --pmc passes: smoltts_byte_150m, B=32 slots, 64 frame-graph replays,
+synchronised every 3 frames, prompts prefilled 8 slots at a time.  It exists because round 1's passes hung on bench.py; the cause
+turned out to be the number of dispatches queued without a synchronisation, not the prefill kernels, and
+since `smoltts_lm_decode` bounds the host's run-ahead (SMOLTTS_MAX_FRAMES_IN_FLIGHT) tools/collect_pmc.sh profiles bench.py itself.
+Kept for comparison with the round-1 numbers."""
 import sys
 
 import torch
