@@ -446,7 +446,8 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
   ST_REQUIRE(a.N >= 4 || a.epilogue == SMOLTTS_EPI_STORE, SMOLTTS_E_INVALID, "gemm: N < 4 only with EPI_STORE");
   ST_REQUIRE((long)((a.M + 63) / 64) <= 65535, SMOLTTS_E_INVALID, "gemm: M=%d too large for one launch", a.M);
   GemmDev d;
-  d.w = (const char*)a.w_dev; d.w3 = (const char*)a.w3_dev; d.x = a.x_dev; d.ldx = a.ldx; d.x_bstride = a.x_bstride;
+  d.w = (const char*)a.w_dev; d.w3 = (const char*)a.w3_dev; d.splitk_ws = a.splitk_ws_dev; d.splitk_cap = a.splitk_ws_floats; d.ksplit = 1;
+  d.x = a.x_dev; d.ldx = a.ldx; d.x_bstride = a.x_bstride;
   d.rows_per_batch = a.rows_per_batch; d.M = a.M; d.N = a.N; d.K = a.K; d.gamma = a.gamma_dev; d.eps = a.eps;
   d.bias = a.bias_dev; d.scale = a.scale_dev; d.resid = a.resid_dev; d.out = a.out_dev; d.ldo = a.ldo;
   d.raw_out = a.raw_out_dev; d.raw_bstride = a.raw_bstride; d.elu_out = a.elu_out;

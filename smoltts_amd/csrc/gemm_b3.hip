@@ -48,9 +48,14 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmDev p) {
   // XCDs instead), so X leaves HBM / the Infinity Cache once, not once per column block (rocprofv3 FETCH_SIZE of the
   // 256 -> 128 ConvTranspose, 5 column blocks: 1.15 GB per 1024 frames with the plain 2-D grid against 0.1 GB of X).
   const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
-  const int cb = kk % p.grid_cb, rb = (kk / p.grid_cb) * 8 + xcd;
+  // split-K (long K, few tiles: the transformer's fc2 at M = 2048): `ksplit` workgroups per tile take consecutive chunk ranges
+  // and store plain partial sums; splitk_reduce_kernel adds them in fixed order and applies the epilogue
+  const int ks = p.ksplit > 1 ? kk % p.ksplit : 0, kt = p.ksplit > 1 ? kk / p.ksplit : kk;
+  const int cb = kt % p.grid_cb, rb = (kt / p.grid_cb) * 8 + xcd;
   if (rb >= p.grid_rb) return;  // the grid is padded to whole groups of 8 row blocks (uniform over the workgroup)
   const int row0 = rb * BM, tile0 = cb * NT;
+  const int nch_all = p.K >> 5;
+  const int c_lo = p.ksplit > 1 ? (int)((long)nch_all * ks / p.ksplit) : 0, c_hi = p.ksplit > 1 ? (int)((long)nch_all * (ks + 1) / p.ksplit) : nch_all;
 
   const float* xsrc[XI];
   int xdst[XI];
@@ -85,8 +90,8 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmDev p) {
 #pragma unroll
     for (int i = 0; i < WI; ++i) wr[i] = wsrc[i] ? *reinterpret_cast<const uint4*>(wsrc[i] + (size_t)c * 3072) : make_uint4(0, 0, 0, 0);
   };
-  fetch(0);
-  for (int c = 0; c < nchunks; ++c) {
+  fetch(c_lo);
+  for (int c = c_lo; c < c_hi; ++c) {
     __syncthreads();  // the previous chunk has been consumed
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmDev p) {
 #pragma unroll
     for (int i = 0; i < WI; ++i) ws[tid + 256 * i] = wr[i];
     __syncthreads();
-    if (c + 1 < nchunks) fetch(c + 1);  // the next chunk's global loads fly under this chunk's MFMAs
+    if (c + 1 < c_hi) fetch(c + 1);  // the next chunk's global loads fly under this chunk's MFMAs
     uint4 xf[TM][3];
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt)
@@ -123,10 +128,30 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmDev p) {
     const long orow = row_off(m, p.rows_per_batch, p.ldo, p.o_bstride);
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
+      const int n0 = (tile0 + wn * TN + t) * 16 + q * 4;
+      if (p.ksplit > 1) {  // (N % 4 == 0 on this path)
+        if (n0 < p.N) *reinterpret_cast<float4*>(p.splitk_ws + ((long)ks * p.M + m) * p.N + n0) = make_float4(acc[t][mt][0], acc[t][mt][1], acc[t][mt][2], acc[t][mt][3]);
+        continue;
+      }
       float v[4] = {acc[t][mt][0], acc[t][mt][1], acc[t][mt][2], acc[t][mt][3]};
-      rows_epilogue<EPI>(p, m, orow, (tile0 + wn * TN + t) * 16 + q * 4, v);
+      rows_epilogue<EPI>(p, m, orow, n0, v);
     }
   }
+}
+
+// out[m][n0..n0+4) = epilogue( sum over the splits, in split order )
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmDev p) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // one float4 of the [M][N] result
+  const int n4 = p.N >> 2;
+  if (i >= (long)p.M * n4) return;
+  const int m = (int)(i / n4), n0 = (int)(i - (long)m * n4) * 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < p.ksplit; ++s) {
+    const float4 t = *reinterpret_cast<const float4*>(p.splitk_ws + ((long)s * p.M + m) * p.N + n0);
+    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+  }
+  rows_epilogue<EPI>(p, m, row_off(m, p.rows_per_batch, p.ldo, p.o_bstride), n0, v);
 }
 
 // Tile choice, measured on the 16 GEMM shapes of a 1024-frame chunk (tools/microbench_b3.py with SMOLTTS_B3_TILE forced):
@@ -143,6 +168,20 @@ static int launch_b3_epi(const GemmDev& d, hipStream_t stream) {
     return dim3((unsigned)(((g.grid_rb + 7) / 8) * 8 * g.grid_cb));
   };
   ST_REQUIRE(blocks(64, 64) < (1L << 30), SMOLTTS_E_INVALID, "gemm_b3: M=%d too large for one launch", d.M);
+  g.ksplit = 1;
+  // long K over few tiles (fc2 of the decoder transformer at M = 2048: 256 tiles x 64 chunks of 0.2 us MFMA each -- one
+  // workgroup per CU, every chunk a full memory round trip): four workgroups per tile, 16 chunks each, + a 4 MB reduce pass
+  if (d.splitk_ws && d.N % 4 == 0 && blocks(64, 64) <= 512 && (d.K >> 5) >= 48 && 4L * d.M * d.N <= d.splitk_cap) {
+    g.ksplit = 4;
+    g.grid_rb = (d.M + 63) / 64;
+    g.grid_cb = (d.N + 63) / 64;
+    const dim3 grid((unsigned)(((g.grid_rb + 7) / 8) * 8 * g.grid_cb * g.ksplit));
+    hipLaunchKernelGGL((gemm_b3_kernel<2, 2, EPI>), grid, dim3(256), 0, stream, g);
+    ST_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3((unsigned)(((long)d.M * (d.N >> 2) + 255) / 256)), dim3(256), 0, stream, g);
+    ST_CHECK_HIP(hipGetLastError());
+    return SMOLTTS_OK;
+  }
   static const int force = [] { const char* e = getenv("SMOLTTS_B3_TILE"); return e ? atoi(e) : 0; }();  // experiments: 44 | 42 | 22
   if (force == 44 || (force == 0 && blocks(128, 128) >= 512 && d.N >= 128)) {
     const dim3 grid = grid1d(128, 128);

@@ -30,6 +30,9 @@ struct GemmDev {
   int n_q_heads, n_kv_heads, cache_len;
   unsigned long long* stamps;  // diagnostic build aid (SMOLTTS debug API); nullptr in production
   int grid_rb, grid_cb;        // gemm_b3: row blocks x column blocks of the (1-D, XCD-aware) launch
+  float* splitk_ws;            // gemm_b3, optional: workspace of splitk_cap floats for split-K partial sums [split][M][N]
+  long splitk_cap;
+  int ksplit;                  // set by the launcher: K split over this many workgroups per tile (1 = no split)
 };
 
 __device__ __forceinline__ long row_off(int m, int rpb, long ld, long bstride) {

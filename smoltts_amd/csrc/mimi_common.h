@@ -11,6 +11,7 @@ struct MimiTransformerBufs {
   float *kc, *vc;                 // [n_layers][slots][8][cache_len][64]
   size_t layer_stride;            // floats between two layers' caches
   const int *row_pos, *row_slot;  // [rows]
+  float* tws = nullptr;           // optional split-K workspace (4 x rows x 512 floats) for the fc2 GEMM of many-row calls
 };
 
 // The 8-layer pre-LayerNorm block stack of codec/transformer.py:109-150 over `rows` rows (`rows_per_slot`

@@ -50,6 +50,7 @@ struct SmolttsMimiSession {
   int B, chunk;
   float* carry[2];   // [B][512] upsample carry (previous frame's RVQ embedding), double-buffered
   float *tx, *tn, *tq, *ta, *th;  // transformer rows [B*2*chunk][512|512|512|512|2048]
+  float* tws;        // split-K partial sums of the fc2 GEMM: [4][B*2*chunk][512]
   float *kc, *vc;    // [n_layers][B][8][max_positions][64]
   int *row_pos, *row_slot;  // [B*2*chunk]
   float* buf[NBUF];
@@ -107,6 +108,7 @@ void carve(SmolttsMimiSession* s, char* base, size_t* total) {
   s->tq = cv.take<float>(R * D);
   s->ta = cv.take<float>(R * D);
   s->th = cv.take<float>(R * FF);
+  s->tws = cv.take<float>(4 * R * D);
   const size_t kv = (size_t)c.n_layers * B * HEADS * c.max_positions * 64;
   s->kc = cv.take<float>(kv);
   s->vc = cv.take<float>(kv);
@@ -217,6 +219,7 @@ int run_mimi_transformer(const char* A, const SmolttsMimiLayerWeights* layers, i
     }
     {
       SmolttsGemmArgs a = mimi_gemm_f32(A + lw.fc2, b.th, FF, R, D, FF, lw.fc23 ? A + lw.fc23 : nullptr);
+      a.splitk_ws_dev = b.tws; a.splitk_ws_floats = b.tws ? (int64_t)4 * R * D : 0;
       a.epilogue = SMOLTTS_EPI_SCALE_RESID; a.scale_dev = (const float*)(A + lw.ls2);
       a.resid_dev = b.tx; a.ldr = D; a.r_bstride = (int64_t)Tt * D; a.rows_per_batch = Tt;
       a.x_bstride = (int64_t)Tt * FF;
@@ -378,6 +381,7 @@ static int decode_chunk_impl(SmolttsMimiSession* s, const int32_t* codes_dev, in
   {
     MimiTransformerBufs tb{s->tx, s->tn, s->tq, s->ta, s->th, s->kc, s->vc, (size_t)s->B * HEADS * c.max_positions * 64,
                            s->row_pos, s->row_slot};
+    tb.tws = s->tws;
     ST_TRY(run_mimi_transformer(A, m->w.layers, c.n_layers, (const float*)(A + m->w.rope), c.max_positions, c.window, tb, R, Tt,
                                 s->buf[0] + (size_t)BUF_HALO[0] * BUF_C[0], (int64_t)s->buf_bstride[0], st));
   }

@@ -57,7 +57,7 @@ class GemmArgs(C.Structure):
         ("elu_out", C.c_int32), ("raw_out_dev", C.c_void_p), ("raw_bstride", C.c_int64), ("rope_dev", C.c_void_p),
         ("row_pos_dev", C.c_void_p), ("row_slot_dev", C.c_void_p), ("k_cache_dev", C.c_void_p),
         ("v_cache_dev", C.c_void_p), ("n_q_heads", C.c_int32), ("n_kv_heads", C.c_int32), ("cache_len", C.c_int32),
-        ("w3_dev", C.c_void_p),
+        ("w3_dev", C.c_void_p), ("splitk_ws_dev", C.c_void_p), ("splitk_ws_floats", C.c_int64),
     ]
 
 

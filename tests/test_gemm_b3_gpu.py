@@ -53,6 +53,26 @@ def test_b3_store_matches_float64_and_the_fp32_kernel(E, ops, M, N, K):
     assert e_new < 2e-6 and e_new < 4 * e_old + 2e-7
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 512, 2048), (1000, 132, 1600), (256, 64, 1536)])
+def test_b3_split_k_is_deterministic_and_matches_float64(E, ops, M, N, K):
+    """Long K over few tiles: four workgroups per tile + a fixed-order reduce pass (the Mimi transformer's fc2 shape first)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g) * torch.logspace(-2, 2, K)[None]
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    res, sc = torch.randn(M, N, generator=g), torch.randn(N, generator=g)
+    ref = res.double() + sc.double() * (x.double() @ w.double().T)
+    w32, w3 = ops.pack_weight(w, fp32=True), ops.pack_weight_w3(w)
+    ws = torch.empty(4 * M * N, device="cuda")
+    kw = dict(w_fp32=True, epilogue=E.EPI_SCALE_RESID, scale=sc.cuda(), resid=res.cuda(), w3=w3)
+    one = ops.linear(x.cuda(), w32, N, **kw).cpu()
+    a = ops.linear(x.cuda(), w32, N, splitk_ws=ws, **kw).cpu()
+    b = ops.linear(x.cuda(), w32, N, splitk_ws=ws, **kw).cpu()
+    assert torch.equal(a, b)
+    assert rel_err(a, ref) < 2e-6 and rel_err(a, ref) < 4 * rel_err(one, ref) + 2e-7
+    small = ops.linear(x.cuda(), w32, N, splitk_ws=ws[: M * N], **kw).cpu()  # workspace too small: the unsplit path, same result as without
+    assert torch.equal(small, one)
+
+
 def test_b3_epilogues(E, ops):
     g = torch.Generator().manual_seed(5)
     M, K, N = 1024, 512, 512

@@ -19,7 +19,8 @@ for name, M, N, K in shapes:
     w32, w3 = ops.pack_weight(w, fp32=True), ops.pack_weight_w3(w)
     out = torch.empty(M, N, device="cuda")
     ts = []
-    for kw in ({}, {"w3": w3}):
+    ws = torch.empty(4 * M * N, device="cuda") if M * N <= 1 << 21 else None
+    for kw in ({}, {"w3": w3, "splitk_ws": ws}):
         for _ in range(2):
             ops.linear(x, w32, N, w_fp32=True, out=out, elu_out=True, **kw)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
