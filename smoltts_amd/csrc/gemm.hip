@@ -450,7 +450,7 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
   d.x = a.x_dev; d.ldx = a.ldx; d.x_bstride = a.x_bstride;
   d.rows_per_batch = a.rows_per_batch; d.M = a.M; d.N = a.N; d.K = a.K; d.gamma = a.gamma_dev; d.eps = a.eps;
   d.bias = a.bias_dev; d.scale = a.scale_dev; d.resid = a.resid_dev; d.out = a.out_dev; d.ldo = a.ldo;
-  d.raw_out = a.raw_out_dev; d.raw_bstride = a.raw_bstride; d.elu_out = a.elu_out;
+  d.raw_out = a.raw_out_dev; d.raw_bstride = a.raw_bstride; d.elu_out = a.elu_out; d.pro_elu = a.prologue == SMOLTTS_PRO_ELU;
   d.o_bstride = a.o_bstride; d.ldr = a.ldr ? a.ldr : a.ldo; d.r_bstride = a.ldr ? a.r_bstride : a.o_bstride;
   d.rope = a.rope_dev; d.row_pos = a.row_pos_dev; d.row_slot = a.row_slot_dev;
   d.kc = a.k_cache_dev; d.vc = a.v_cache_dev; d.n_q_heads = a.n_q_heads; d.n_kv_heads = a.n_kv_heads;
@@ -487,7 +487,7 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
     const int WN = per >= 4 ? 4 : (per >= 2 ? 2 : 1);
     rows_grid = (long)((per + WN - 1) / WN) * ((a.M + 64 * (4 / WN) - 1) / (64 * (4 / WN)));
   }
-  if (a.w_is_fp32 && a.w3_dev && P == SMOLTTS_PRO_NONE && gemm_b3_applies(a.M, a.N, a.K, E) && !(E == SMOLTTS_EPI_STORE && a.N < 4))
+  if (a.w_is_fp32 && a.w3_dev && (P == SMOLTTS_PRO_NONE || P == SMOLTTS_PRO_ELU) && gemm_b3_applies(a.M, a.N, a.K, E) && !(E == SMOLTTS_EPI_STORE && a.N < 4))
     return launch_gemm_b3(d, E, stream);
   if (a.w_is_fp32 && P == SMOLTTS_PRO_NONE && a.M >= 1024 && rows_grid >= 192) {
     ST_REQUIRE((long)((a.M + 63) / 64) <= 65535 * 4L, SMOLTTS_E_INVALID, "gemm: M=%d too large for one launch", a.M);

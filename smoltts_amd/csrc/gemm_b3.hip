@@ -30,6 +30,7 @@ __device__ __forceinline__ int xs_slot(int pc, int q, int row, int BM) {
   const int mask = q == 0 ? 0 : (q == 1 ? 3 : (q == 2 ? 12 : 15));
   return (pc * 4 + q) * BM + (row & ~15) + ((row & 15) ^ mask);
 }
+__device__ __forceinline__ float elu_hw1(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
 }  // namespace
 
 template <int TM, int TN, int EPI>
@@ -47,12 +48,15 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmDev p) {
   // blocks of one row block all read the same X rows: they get consecutive slots on ONE XCD (row blocks are dealt over the
   // XCDs instead), so X leaves HBM / the Infinity Cache once, not once per column block (rocprofv3 FETCH_SIZE of the
   // 256 -> 128 ConvTranspose, 5 column blocks: 1.15 GB per 1024 frames with the plain 2-D grid against 0.1 GB of X).
+  // Where W is the larger operand (conv0, the first ConvTranspose: 22 / 50 MB of W3 against 4 / 16 MB of X) the roles swap
+  // (xcd_cols): column blocks are dealt over the XCDs, so each XCD reads 1/8 of W and all of X instead of all of W.
   const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
   // split-K (long K, few tiles: the transformer's fc2 at M = 2048): `ksplit` workgroups per tile take consecutive chunk ranges
   // and store plain partial sums; splitk_reduce_kernel adds them in fixed order and applies the epilogue
   const int ks = p.ksplit > 1 ? kk % p.ksplit : 0, kt = p.ksplit > 1 ? kk / p.ksplit : kk;
-  const int cb = kt % p.grid_cb, rb = (kt / p.grid_cb) * 8 + xcd;
-  if (rb >= p.grid_rb) return;  // the grid is padded to whole groups of 8 row blocks (uniform over the workgroup)
+  const int cb = p.xcd_cols ? (kt / p.grid_rb) * 8 + xcd : kt % p.grid_cb;
+  const int rb = p.xcd_cols ? kt % p.grid_rb : (kt / p.grid_cb) * 8 + xcd;
+  if (rb >= p.grid_rb || cb >= p.grid_cb) return;  // the grid is padded to whole groups of 8 blocks (uniform over the workgroup)
   const int row0 = rb * BM, tile0 = cb * NT;
   const int nch_all = p.K >> 5;
   const int c_lo = p.ksplit > 1 ? (int)((long)nch_all * ks / p.ksplit) : 0, c_hi = p.ksplit > 1 ? (int)((long)nch_all * (ks + 1) / p.ksplit) : nch_all;
@@ -81,7 +85,12 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmDev p) {
 
   float4 xr[XI][2];
   uint4 wr[WI];
-  auto fetch = [&](int c) {
+  // chunk number -> 32-k chunk of K.  Conv windows overlap (row m's tap t + 1 is row m + 1's tap t): taken in K order the
+  // same X bytes come back `taps` times, K / taps chunks apart -- long gone from L1 and, with 64 workgroups per XCD, from
+  // L2.  Visiting the taps of one channel slice back to back makes the repeats hits.
+  auto kchunk = [&](int c) { return p.taps > 1 ? (c % p.taps) * p.cpt + c / p.taps : c; };
+  auto fetch = [&](int cn) {
+    const int c = kchunk(cn);
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       xr[i][0] = xsrc[i] ? *reinterpret_cast<const float4*>(xsrc[i] + c * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -96,6 +105,12 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmDev p) {
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       uint4 h, m, l;
+      if (p.pro_elu) {  // the hardware exponential: see seanet.hip (absolute error ~6e-8 on O(1) activations)
+        float4& a = xr[i][0];
+        float4& b = xr[i][1];
+        a = make_float4(elu_hw1(a.x), elu_hw1(a.y), elu_hw1(a.z), elu_hw1(a.w));
+        b = make_float4(elu_hw1(b.x), elu_hw1(b.y), elu_hw1(b.z), elu_hw1(b.w));
+      }
       split3x8(xr[i][0], xr[i][1], h, m, l);
       xs[xdst[i]] = h;
       xs[xdst[i] + 4 * BM] = m;
@@ -162,10 +177,19 @@ template <int EPI>
 static int launch_b3_epi(const GemmDev& d, hipStream_t stream) {
   auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
   GemmDev g = d;
-  auto grid1d = [&](int bm, int bn) {  // 8 consecutive ids = 8 XCDs = 8 different row blocks, see the kernel
+  static const int env_taps = [] { const char* e = getenv("SMOLTTS_B3_TAPS"); return e ? atoi(e) : 1; }();  // experiments: 0 = K order
+  static const int env_xcd = [] { const char* e = getenv("SMOLTTS_B3_XCD"); return e ? atoi(e) : -1; }();   // experiments: 0 rows | 1 columns
+  g.taps = 1; g.cpt = d.K >> 5;
+  if (env_taps && d.ldx < d.K && d.ldx % 32 == 0 && d.K % d.ldx == 0) { g.taps = (int)(d.K / d.ldx); g.cpt = (int)(d.ldx >> 5); }
+  const double x_bytes = 4.0 * d.M * (d.ldx < d.K ? d.ldx : d.K), w_bytes = 6.0 * d.N * d.K;
+  auto grid1d = [&](int bm, int bn) {  // 8 consecutive ids = 8 XCDs = 8 different row (or column) blocks, see the kernel
     g.grid_rb = (d.M + bm - 1) / bm;
     g.grid_cb = (d.N + bn - 1) / bn;
-    return dim3((unsigned)(((g.grid_rb + 7) / 8) * 8 * g.grid_cb));
+    const double by_rows = x_bytes + (g.grid_rb < 8 ? g.grid_rb : 8) * w_bytes, by_cols = (g.grid_cb < 8 ? g.grid_cb : 8) * x_bytes + w_bytes;
+    // (a dimension dealt over the XCDs must fill them evenly: whole groups of 8 column blocks)
+    g.xcd_cols = env_xcd >= 0 ? env_xcd : (g.grid_cb % 8 == 0 && by_cols < by_rows);
+    const long blocks8 = g.xcd_cols ? (long)((g.grid_cb + 7) / 8) * 8 * g.grid_rb : (long)((g.grid_rb + 7) / 8) * 8 * g.grid_cb;
+    return dim3((unsigned)(blocks8 * g.ksplit));
   };
   ST_REQUIRE(blocks(64, 64) < (1L << 30), SMOLTTS_E_INVALID, "gemm_b3: M=%d too large for one launch", d.M);
   g.ksplit = 1;
@@ -173,9 +197,7 @@ static int launch_b3_epi(const GemmDev& d, hipStream_t stream) {
   // workgroup per CU, every chunk a full memory round trip): four workgroups per tile, 16 chunks each, + a 4 MB reduce pass
   if (d.splitk_ws && d.N % 4 == 0 && blocks(64, 64) <= 512 && (d.K >> 5) >= 48 && 4L * d.M * d.N <= d.splitk_cap) {
     g.ksplit = 4;
-    g.grid_rb = (d.M + 63) / 64;
-    g.grid_cb = (d.N + 63) / 64;
-    const dim3 grid((unsigned)(((g.grid_rb + 7) / 8) * 8 * g.grid_cb * g.ksplit));
+    const dim3 grid = grid1d(64, 64);
     hipLaunchKernelGGL((gemm_b3_kernel<2, 2, EPI>), grid, dim3(256), 0, stream, g);
     ST_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3((unsigned)(((long)d.M * (d.N >> 2) + 255) / 256)), dim3(256), 0, stream, g);

@@ -21,6 +21,7 @@ struct GemmDev {
   float* raw_out;  // optional copy of the un-activated result (same row stride, own batch stride)
   long raw_bstride;
   int elu_out;     // apply ELU to what goes to `out`
+  int pro_elu;     // gemm_b3: apply ELU to X as it is staged (the producer stored the raw tensor only)
   long ldr, r_bstride;
   const float* rope;
   const int* row_pos;
@@ -33,6 +34,9 @@ struct GemmDev {
   float* splitk_ws;            // gemm_b3, optional: workspace of splitk_cap floats for split-K partial sums [split][M][N]
   long splitk_cap;
   int ksplit;                  // set by the launcher: K split over this many workgroups per tile (1 = no split)
+  int taps, cpt;               // set by the launcher: conv windows (K = taps * ldx, overlapping rows): 32-k chunks are visited channel
+                               // slice by channel slice, all taps of a slice back to back; cpt = chunks per tap.  taps = 1: in order
+  int xcd_cols;                // set by the launcher: 1 = the XCDs are dealt column blocks (W leaves memory once), 0 = row blocks (X does)
 };
 
 __device__ __forceinline__ long row_off(int m, int rpb, long ld, long bstride) {

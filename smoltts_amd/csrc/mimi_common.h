@@ -25,20 +25,30 @@ int run_mimi_transformer(const char* arena, const SmolttsMimiLayerWeights* layer
 int launch_mimi_rows(int n_rows, int rows_per_slot, int pos0, int* row_pos, int* row_slot, hipStream_t st,
                      const int* slot_pos = nullptr);
 
-// Fused resnet block of a SEANet decoder stage (seanet.hip): x = raw ConvTranspose output, channel-last, with 2 halo rows
-// (4 when final_conv) in front of every slot's rows; writes ELU(x + conv1(ELU(conv3(ELU(x))))) to `out`, or, with
-// final_conv, the PCM samples of the output convolution over it.
+// Fused resnet block of a SEANet decoder stage (seanet.hip): x = raw ConvTranspose output, channel-last, with 2 halo rows in
+// front of every slot's rows; writes ELU(x + conv1(ELU(conv3(ELU(x))))) to `out`.
 struct MimiResblockArgs {
-  int channels, final_conv, batch, T;
+  int channels, batch, T;
   const float* x; int64_t x_bstride;
   const void* w2; const float* b2;   // conv k3: W3 tiles of [C/2][3C], bias
   const void* w3; const float* b3;   // conv k1: W3 tiles of [C][C/2], bias
   float* out; int64_t o_bstride;
-  const float* final_w; float final_b;  // output conv k3 C -> 1: fp32 [3][C]
+};
+int launch_seanet_resblock(const MimiResblockArgs& a, hipStream_t st);
+
+// The whole last SEANet stage (seanet_last.hip): ConvTranspose 128 -> 64 (stride 4) + resnet block + ELU + output conv -> PCM.
+// `in` = ELU(stage-3 output), channel-last, with 2 halo rows (the previous call's last rows) in front of every slot's rows.
+struct MimiLastStageArgs {
+  int batch, T;                        // slots, input rows per slot (4 T samples each)
+  const float* in; int64_t in_bstride;
+  const void* wt; const float* bt;     // ConvTranspose as GEMM [256][256]: W3 tiles, bias [256]
+  const void* w2; const float* b2;     // conv k3 64 -> 32: W3 tiles of [32][192], bias
+  const void* w3; const float* b3;     // conv k1 32 -> 64: W3 tiles of [64][32], bias
+  const float* final_w; float final_b; // output conv k3 64 -> 1: fp32 [3][64]
   float* pcm; int64_t pcm_stride;
   const int* slot_pos;
 };
-int launch_seanet_resblock(const MimiResblockArgs& a, hipStream_t st);
+int launch_seanet_last(const MimiLastStageArgs& a, hipStream_t st);
 
 inline SmolttsGemmArgs mimi_gemm_f32(const void* w, const float* x, long ldx, int M, int N, int K, const void* w3 = nullptr) {
   SmolttsGemmArgs a;

@@ -27,13 +27,15 @@ constexpr int SAMPLES = 1920;
 // buffer i feeds conv i (i < 13); channels, halo rows and rows per frame of each conv input
 // conv order: conv0 | convT1 res1.c3 res1.c1 | convT2 ... | convT4 res4.c3 res4.c1 | final
 constexpr int BUF_C[NBUF] = {512, 1024, 512, 256, 512, 256, 128, 256, 128, 64, 128, 64, 32, 64};
-// Stages 3 and 4 run their resnet block fused (seanet.hip): buffers 8 and 11 then hold the RAW ConvTranspose output (the block
-// recomputes ELU and the rows it needs of the previous tile), buffer 11 with 4 halo rows (2 for the block's k3 conv + 2 for the
-// output conv applied in the same kernel); buffers 9, 12, 13 are unused.
-constexpr int BUF_HALO[NBUF] = {6, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 4, 0, 2};
-constexpr bool FUSED_BLOCK[NCONV] = {false, false, false, false, false, false, false, false, true, false, false, true, false, false};
-// a fused block's inner tensors (the hidden; for the last stage also the block output) never exist in HBM
-constexpr bool buf_used(int i) { return !((i >= 1 && FUSED_BLOCK[i - 1]) || (i == NBUF - 1 && FUSED_BLOCK[NBUF - 3])); }
+// The resnet blocks take the RAW ConvTranspose output (buffers 2, 5, 8): the residual needs it and the block's first conv applies
+// ELU on the way in.  Stage 3 runs its block fused (seanet.hip: the hidden, buffer 9, never exists).  Stage 4 is one kernel from
+// its ConvTranspose to the PCM samples (seanet_last.hip, convs 10 .. 13): it reads buffer 10 with 2 halo rows (one for the
+// ConvTranspose's second tap + one because a tile recomputes the 4 rows in front of it: 2 for the block's k3 conv + 2 for the
+// output conv); buffers 11 .. 13 never exist.
+constexpr int BUF_HALO[NBUF] = {6, 1, 2, 0, 1, 2, 0, 1, 2, 0, 2, 0, 0, 0};
+constexpr bool FUSED_BLOCK[NCONV] = {false, false, false, false, false, false, false, false, true, false, false, false, false, false};
+constexpr int LAST_STAGE = 10;  // first conv of the stage that runs as one kernel
+constexpr bool buf_used(int i) { return i <= LAST_STAGE && !(i >= 1 && FUSED_BLOCK[i - 1]); }
 constexpr int BUF_RPF[NBUF] = {2, 2, 16, 16, 16, 96, 96, 96, 480, 480, 480, 1920, 1920, 1920};
 // buffer index feeding each conv (conv c reads BUF[c]; writes BUF[c+1], the last writes pcm)
 }  // namespace
@@ -55,8 +57,6 @@ struct SmolttsMimiSession {
   int *row_pos, *row_slot;  // [B*2*chunk]
   float* buf[NBUF];
   size_t buf_bstride[NBUF];  // floats per slot
-  float* raw[4];             // un-activated ConvTranspose outputs (residual inputs of the 4 resnet blocks)
-  size_t raw_bstride[4];
   size_t halo_total;         // bytes of everything that reset must zero: tracked via pointers below
   char* zero_begin;
   size_t zero_bytes;
@@ -97,11 +97,6 @@ void carve(SmolttsMimiSession* s, char* base, size_t* total) {
   }
   s->zero_begin = base ? base + z0 : nullptr;
   s->zero_bytes = cv.off - z0;
-  for (int j = 0; j < 4; ++j) {  // raw copies of buffers 2, 5 (8, 11: the fused blocks read the raw tensor itself); no halo
-    const int i = 2 + 3 * j;
-    s->raw_bstride[j] = FUSED_BLOCK[i] ? 0 : (size_t)BUF_RPF[i] * F * BUF_C[i];
-    s->raw[j] = cv.take<float>(B * s->raw_bstride[j]);
-  }
   // --- scratch / caches (need no zeroing: only positions < `positions` are ever read)
   s->tx = cv.take<float>(R * D);
   s->tn = cv.take<float>(R * D);
@@ -247,7 +242,7 @@ int smoltts_mimi_create(const SmolttsMimiConfig* cfg, const SmolttsMimiWeights* 
   for (int i = 0; i < NCONV; ++i) {
     const SmolttsMimiConv& cv = offsets->convs[i];
     ST_REQUIRE(cv.cin == BUF_C[i] && (i + 1 == NCONV ? cv.cout == 1 : (cv.transposed ? cv.cout : cv.cout) == BUF_C[i + 1]) &&
-                   (cv.transposed ? (cv.k == 2 * cv.stride && BUF_HALO[i] == 1) : (cv.stride == 1 && (FUSED_BLOCK[i] || BUF_HALO[i] == cv.k - 1))) && cv.w % 16 == 0 && cv.b % 16 == 0 && cv.w < arena_bytes && cv.b < arena_bytes,
+                   (cv.transposed ? (cv.k == 2 * cv.stride && BUF_HALO[i] >= 1) : (cv.stride == 1 && (i > LAST_STAGE || BUF_HALO[i] == cv.k - 1))) && cv.w % 16 == 0 && cv.b % 16 == 0 && cv.w < arena_bytes && cv.b < arena_bytes,
                SMOLTTS_E_INVALID, "mimi_create: conv %d descriptor inconsistent (cin=%d)", i, cv.cin);
   }
   ST_REQUIRE(offsets->rvq_table + (size_t)cfg->num_codebooks * 2048 * D * 4 <= arena_bytes &&
@@ -386,35 +381,45 @@ static int decode_chunk_impl(SmolttsMimiSession* s, const int32_t* codes_dev, in
                                 s->buf[0] + (size_t)BUF_HALO[0] * BUF_C[0], (int64_t)s->buf_bstride[0], st));
   }
 
-  // 3. SEANet decoder (seanet.py:105-139) as 14 GEMMs over halo-prefixed channel-last buffers.
-  //    Every buffer holds ELU(activation) (each consumer applies ELU first, seanet.py:16-20,117-137), so the
-  //    activation is computed once by the producer; the un-activated ConvTranspose output is kept
-  //    beside it for the resnet block's residual add.
+  // 3. SEANet decoder (seanet.py:105-139): GEMMs over halo-prefixed channel-last buffers + the fused kernels of stages 3, 4.
+  //    A buffer holds ELU(activation) (each consumer applies ELU first, seanet.py:16-20,117-137: computed once, by the
+  //    producer) except the ConvTranspose outputs, which stay raw for their resnet block.
   for (int i = 0; i < NCONV; ++i) {
     const SmolttsMimiConv& cv = m->w.convs[i];
-    if (FUSED_BLOCK[i]) {  // resnet block i, i+1 (and, for the last stage, the output conv i+2) in one kernel
+    if (i == LAST_STAGE) {  // ConvTranspose i, resnet block i+1, i+2 and the output conv i+3 in one kernel
+      const SmolttsMimiConv &c2 = m->w.convs[i + 1], &c3 = m->w.convs[i + 2];
+      ST_REQUIRE(cv.w3 && c2.w3 && c3.w3 && m->w.final_w && cv.cin == 128 && cv.cout == 64 && cv.stride == 4, SMOLTTS_E_INVALID,
+                 "mimi: the arena lacks the W3 tiles of the last stage (or its shape is not 128 -> 64, stride 4)");
+      MimiLastStageArgs a;
+      memset(&a, 0, sizeof(a));
+      a.batch = batch; a.T = BUF_RPF[i] * F;
+      a.in = s->buf[i] + (size_t)BUF_HALO[i] * BUF_C[i]; a.in_bstride = (int64_t)s->buf_bstride[i];
+      a.wt = A + cv.w3; a.bt = (const float*)(A + cv.b);
+      a.w2 = A + c2.w3; a.b2 = (const float*)(A + c2.b); a.w3 = A + c3.w3; a.b3 = (const float*)(A + c3.b);
+      a.final_w = (const float*)(A + m->w.final_w); a.final_b = s->final_bias; a.pcm = pcm_dev; a.pcm_stride = pcm_stride;
+      a.slot_pos = s->pos_dev;
+      ST_TRY(launch_seanet_last(a, st));
+      break;
+    }
+    if (FUSED_BLOCK[i]) {  // resnet block i, i+1 in one kernel
       const SmolttsMimiConv& c1 = m->w.convs[i + 1];
-      const bool last = i + 3 == NCONV;
-      ST_REQUIRE(cv.w3 && c1.w3 && (!last || m->w.final_w), SMOLTTS_E_INVALID, "mimi: the arena lacks the W3 tiles of conv %d", i);
+      ST_REQUIRE(cv.w3 && c1.w3, SMOLTTS_E_INVALID, "mimi: the arena lacks the W3 tiles of conv %d", i);
       MimiResblockArgs a;
       memset(&a, 0, sizeof(a));
-      a.channels = cv.cin; a.final_conv = last; a.batch = batch; a.T = BUF_RPF[i] * F;
+      a.channels = cv.cin; a.batch = batch; a.T = BUF_RPF[i] * F;
       a.x = s->buf[i] + (size_t)BUF_HALO[i] * BUF_C[i]; a.x_bstride = (int64_t)s->buf_bstride[i];
       a.w2 = A + cv.w3; a.b2 = (const float*)(A + cv.b); a.w3 = A + c1.w3; a.b3 = (const float*)(A + c1.b);
-      if (last) {
-        a.final_w = (const float*)(A + m->w.final_w); a.final_b = s->final_bias; a.pcm = pcm_dev; a.pcm_stride = pcm_stride;
-        a.slot_pos = s->pos_dev;
-      } else {
-        a.out = s->buf[i + 2] + (size_t)BUF_HALO[i + 2] * BUF_C[i + 2]; a.o_bstride = (int64_t)s->buf_bstride[i + 2];
-      }
+      a.out = s->buf[i + 2] + (size_t)BUF_HALO[i + 2] * BUF_C[i + 2]; a.o_bstride = (int64_t)s->buf_bstride[i + 2];
       ST_TRY(launch_seanet_resblock(a, st));
-      i += last ? 2 : 1;
+      i += 1;
       continue;
     }
     const int Tin = BUF_RPF[i] * F;
     const int K = cv.transposed ? 2 * cv.cin : cv.k * cv.cin;
     const int N = cv.transposed ? cv.stride * cv.cout : cv.cout;
-    SmolttsGemmArgs a = mimi_gemm_f32(A + cv.w, s->buf[i], cv.cin, batch * Tin, N, K, cv.w3 ? A + cv.w3 : nullptr);
+    // the GEMM window of row t starts k - 1 (ConvTranspose: 1) rows before it; a buffer may carry more halo rows than that
+    const int lead = BUF_HALO[i] - (cv.transposed ? 1 : cv.k - 1);
+    SmolttsGemmArgs a = mimi_gemm_f32(A + cv.w, s->buf[i] + (size_t)lead * cv.cin, cv.cin, batch * Tin, N, K, cv.w3 ? A + cv.w3 : nullptr);
     a.rows_per_batch = Tin; a.x_bstride = (int64_t)s->buf_bstride[i];
     a.bias_dev = (const float*)(A + cv.b);
     a.prologue = SMOLTTS_PRO_NONE;
@@ -422,20 +427,17 @@ static int decode_chunk_impl(SmolttsMimiSession* s, const int32_t* codes_dev, in
     if (i + 1 < NCONV) {
       a.out_dev = s->buf[i + 1] + (size_t)BUF_HALO[i + 1] * BUF_C[i + 1];
       a.ldo = N; a.o_bstride = (int64_t)s->buf_bstride[i + 1];
-      a.elu_out = FUSED_BLOCK[i + 1] ? 0 : 1;  // a fused block takes the raw tensor
+      a.elu_out = cv.transposed ? 0 : 1;  // a resnet block takes the raw tensor: its residual needs it, its first conv applies ELU
     } else {
       a.out_dev = pcm_dev; a.ldo = 1; a.o_bstride = pcm_stride;
     }
-    if (cv.transposed && !FUSED_BLOCK[i + 1]) {  // i = 1, 4 -> raw copy j = (i - 1) / 3 for the (unfused) block's residual
-      const int j = (i - 1) / 3;
-      a.raw_out_dev = s->raw[j]; a.raw_bstride = (int64_t)s->raw_bstride[j];
-    }
-    const bool res_c1 = i >= 3 && i <= 12 && (i % 3) == 0;  // second conv of a residual block: + block input
+    const bool res_c3 = i >= 2 && i <= 11 && (i % 3) == 2;  // first conv of a residual block: ELU on the way in
+    if (res_c3) a.prologue = SMOLTTS_PRO_ELU;
+    const bool res_c1 = i >= 3 && i <= 12 && (i % 3) == 0;  // second conv of a residual block: + block input (two buffers back)
     if (res_c1) {
-      const int j = i / 3 - 1;
       a.epilogue = SMOLTTS_EPI_RESID;
-      a.resid_dev = s->raw[j];
-      a.ldr = BUF_C[i - 1]; a.r_bstride = (int64_t)s->raw_bstride[j];
+      a.resid_dev = s->buf[i - 1] + (size_t)BUF_HALO[i - 1] * BUF_C[i - 1];
+      a.ldr = BUF_C[i - 1]; a.r_bstride = (int64_t)s->buf_bstride[i - 1];
     }
     ST_TRY(launch_gemm(a, st));
   }

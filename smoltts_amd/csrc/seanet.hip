@@ -1,18 +1,17 @@
-// Fused SEANet resnet block (and, for the last stage, the output convolution) of the Mimi decoder.
+// Fused SEANet resnet block of the Mimi decoder (stage 3; the last stage is seanet_last.hip).
 //
 // Reference: MimiResnetBlock (mlx_inference/src/smoltts_mlx/codec/seanet.py:8-49, dilation 1):
 //   y = x + Conv1d_k1( ELU( Conv1d_k3( ELU(x) ) ) ),   C -> C/2 -> C channels, causal (left zero padding of ELU(x)),
-// followed in MimiDecoder (seanet.py:99-139) by ELU and either the next ConvTranspose1d or, after the last block,
-// Conv1d k3 (64 -> 1) to PCM.
+// followed in MimiDecoder (seanet.py:99-139) by ELU and the next ConvTranspose1d.
 //
-// Unfused, the two late stages move the block's tensors through HBM five times per 1024 frames (raw + ELU copy of x, the
-// hidden, y, the residual re-read: ~3.5 GB at 64 channels x 1.97 M rows, ~1.8 GB at 128 x 0.49 M) for 10 % of the FLOPs.
+// Unfused, the block's tensors move through HBM five times per 1024 frames (raw + ELU copy of x, the hidden, y, the
+// residual re-read: ~1.8 GB at 128 channels x 0.49 M rows) for 10 % of the FLOPs.
 // Here one workgroup takes RC consecutive rows of one slot: x (raw ConvTranspose output) is read once, ELU(x) is split
 // into bf16x3 pieces in LDS (gemm_dev.h: fp32-grade products on the bf16 matrix cores), both convolutions run as
 // 16x16x32 MFMAs over LDS-resident operands with the weights staged through LDS in groups of 32-k chunks, the hidden
-// never leaves LDS, and only ELU(y) -- or, in the last stage, the PCM samples -- is written.  The causal k3 windows of
-// a tile need 2 rows (4 with the output conv) of the previous tile: recomputed from x, whose halo rows in front of the
-// buffer carry the previous call's last rows (streaming), so chunked decoding equals decoding in one call.
+// never leaves LDS, and only ELU(y) is written.  The causal k3 windows of a tile need 2 rows of the previous tile: read
+// again from x, whose halo rows in front of the buffer carry the previous call's last rows (streaming), so chunked
+// decoding equals decoding in one call.
 #include "gemm_dev.h"
 #include "mimi_common.h"
 
@@ -21,20 +20,15 @@ namespace smoltts {
 namespace {
 
 struct ResDev {
-  const float* x;   // raw block input, row 0 of slot 0; HX = 2 (4 with FINAL) halo rows sit in front of every slot's rows
+  const float* x;   // raw block input, row 0 of slot 0; 2 halo rows sit in front of every slot's rows
   long x_bstride;   // floats per slot
   int T;            // rows per slot in this call
   const char* w2;   // conv k3, C -> C/2, as W3 tiles of the GEMM matrix [C/2][3C] (k = tap * C + channel)
   const float* b2;
   const char* w3;   // conv k1, C/2 -> C, as W3 tiles of [C][C/2]
   const float* b3;
-  float* out;       // !FINAL: ELU(y), row 0 of slot 0 of the next stage's input buffer
+  float* out;       // ELU(y), row 0 of slot 0 of the next stage's input buffer
   long o_bstride;
-  const float* wf;  // FINAL: output conv k3, C -> 1: fp32 [3][C] (tap-major), bias bf
-  float bf;
-  float* pcm;
-  long pcm_stride;
-  const int* slot_pos;  // FINAL: [slots] stream position before this call (0: the stream starts here -> rows before it are padding)
 };
 
 // Tiles are kept small on purpose: a tile is a chain of dependent memory round trips (x, weight groups, residual) with
@@ -45,9 +39,9 @@ struct ResDev {
 // ELU to every element of x, of the hidden and of y: with expm1f the vector units, not the matrix cores, bound the kernel).
 __device__ __forceinline__ float elu_fast(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
 
-template <int C, int RC, bool FINAL, int NW>
+template <int C, int RC, int NW>
 struct ResCfg {
-  static constexpr int H = C / 2, HY = FINAL ? 2 : 0, RT = RC - HY, RL = RC + 2, RLP = (RL + 15) / 16 * 16;
+  static constexpr int H = C / 2, RT = RC, RL = RC + 2, RLP = (RL + 15) / 16 * 16;
   static constexpr int CC = C / 32, HC = H / 32, K2C = 3 * CC;
   static constexpr int NT2 = H / 16, NT3 = C / 16, MT = RC / 16;
   static constexpr int WR = MT < NW ? MT : NW, WC = NW / WR;  // wave arrangement: row tiles x column groups
@@ -58,25 +52,23 @@ struct ResCfg {
   static constexpr size_t LDS = (size_t)(HP_U4 + VP_U4) * 16 + WB_BYTES;
   static_assert(MT % WR == 0 && NW % WR == 0 && NT2 % WC == 0 && NT3 % WC == 0, "wave arrangement");
   static_assert(K2C % GK2 == 0 && NT2 * GK2 * 3072 <= WB_BYTES && NT3 * GK3 * 3072 <= WB_BYTES, "weight groups");
-  static_assert(!FINAL || (RC * C * 4 <= HP_U4 * 16 && 4 * RT <= NW * 64), "FINAL: ELU(y) aliases the ELU(x) pieces; 4 threads per sample");
 };
 
-template <int C, int RC, bool FINAL, int NW>
+template <int C, int RC, int NW>
 __global__ __launch_bounds__(NW * 64) void resblock_kernel(ResDev p) {
-  using K = ResCfg<C, RC, FINAL, NW>;
+  using K = ResCfg<C, RC, NW>;
   constexpr int NTHR = NW * 64;
-  constexpr int H = K::H, HY = K::HY, RT = K::RT, RL = K::RL, RLP = K::RLP, CC = K::CC, HC = K::HC, K2C = K::K2C;
+  constexpr int H = K::H, RT = K::RT, RL = K::RL, RLP = K::RLP, CC = K::CC, HC = K::HC, K2C = K::K2C;
   constexpr int NT2 = K::NT2, NT3 = K::NT3, MT = K::MT, WR = K::WR, WC = K::WC;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* hp = reinterpret_cast<uint4*>(smem);                  // ELU(x) pieces [piece][x chunk][q][row]
   uint4* vp = hp + K::HP_U4;                                   // ELU(hidden) pieces [piece][h chunk][q][row]
   uint4* wb = vp + K::VP_U4;                                   // weight group [col tile][chunk in group][piece][lane]
-  float* ey = reinterpret_cast<float*>(smem);                  // FINAL: ELU(y) [row][C], over the (dead) ELU(x) pieces
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, q = lane >> 4;
   const int b = blockIdx.y;
   const int u0 = blockIdx.x * RT;   // first output row of the tile
-  const int cu0 = u0 - HY;          // first computed row (y); x rows cu0 - 2 .. cu0 + RC - 1 are loaded
+  const int cu0 = u0;               // first computed row (y); x rows cu0 - 2 .. cu0 + RC - 1 are loaded
   const float* xb = p.x + (long)b * p.x_bstride;
   const int wr = wave % WR, wc = wave / WR;
 
@@ -101,8 +93,11 @@ __global__ __launch_bounds__(NW * 64) void resblock_kernel(ResDev p) {
 
   // ---- phase 0: x -> ELU -> bf16x3 pieces in LDS (the first weight group rides along)
   ST_FETCH_W(p.w2, NT2, K2C, 0, K::GK2)
-  for (int idx = tid; idx < RL * (C / 8); idx += NTHR) {
-    const int lr = idx / (C / 8), g8 = idx - lr * (C / 8);
+  // 8 consecutive lanes take 8 consecutive rows of one 8-channel group: 128 contiguous LDS bytes per ds_write_b128 lane group
+  // (lanes along the channel groups would put all 8 on one bank: the planes are a multiple of 256 B apart)
+  for (int idx = tid; idx < (RL + 7) / 8 * 8 * (C / 8); idx += NTHR) {
+    const int lr = idx / (C / 8 * 8) * 8 + (idx & 7), g8 = (idx >> 3) % (C / 8);
+    if (lr >= RL) continue;
     const int row = cu0 - 2 + lr;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
     if (row < p.T) {
@@ -185,7 +180,6 @@ __global__ __launch_bounds__(NW * 64) void resblock_kernel(ResDev p) {
   }
 
   // ---- phase C: y = conv k1 over ELU(hidden) + x
-  const bool stream_start = FINAL && p.slot_pos[b] == 0 && blockIdx.x == 0;
   {
     constexpr int RW = MT / WR, CW = NT3 / WC, G3 = HC / K::GK3;
     f32x4 acc[RW][CW];
@@ -227,7 +221,6 @@ __global__ __launch_bounds__(NW * 64) void resblock_kernel(ResDev p) {
         __syncthreads();
       }
     }
-    if (FINAL) __syncthreads();  // ELU(y) overwrites the ELU(x) pieces and nothing may still be reading LDS operands of this phase
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
       const int row = (wr + i * WR) * 16 + r, grow = cu0 + row;
@@ -240,12 +233,7 @@ __global__ __launch_bounds__(NW * 64) void resblock_kernel(ResDev p) {
           e = make_float4(elu_fast(acc[i][j][0] + bb.x + xr.x), elu_fast(acc[i][j][1] + bb.y + xr.y), elu_fast(acc[i][j][2] + bb.z + xr.z),
                           elu_fast(acc[i][j][3] + bb.w + xr.w));
         }
-        if (FINAL) {
-          if (stream_start && grow < 0) e = make_float4(0.f, 0.f, 0.f, 0.f);  // before the stream: the output conv's zero padding
-          *reinterpret_cast<float4*>(ey + row * C + n) = e;
-        } else if (grow < p.T) {
-          *reinterpret_cast<float4*>(p.out + (long)b * p.o_bstride + (long)grow * C + n) = e;
-        }
+        if (grow < p.T) *reinterpret_cast<float4*>(p.out + (long)b * p.o_bstride + (long)grow * C + n) = e;
       }
     }
   }
@@ -253,41 +241,19 @@ __global__ __launch_bounds__(NW * 64) void resblock_kernel(ResDev p) {
 #undef ST_FETCH_W
 #undef ST_STORE_W
 
-  // ---- phase D (last stage): PCM sample u0 + i = bf + sum_{tap, c} wf[tap][c] * ELU(y)[i + tap][c]; 4 threads per sample
-  if (FINAL) {
-    __syncthreads();
-    const int i = tid >> 2, part = tid & 3;
-    float s = 0.f;
-    if (i < RT) {
-#pragma unroll
-      for (int tap = 0; tap < 3; ++tap) {
-        const float* er = ey + (i + tap) * C + part * (C / 4);
-        const float* wr_ = p.wf + tap * C + part * (C / 4);
-#pragma unroll
-        for (int c4 = 0; c4 < C / 16; ++c4) {
-          const float4 ev = *reinterpret_cast<const float4*>(er + c4 * 4);
-          const float4 wv = *reinterpret_cast<const float4*>(wr_ + c4 * 4);
-          s = fmaf(ev.x, wv.x, s); s = fmaf(ev.y, wv.y, s); s = fmaf(ev.z, wv.z, s); s = fmaf(ev.w, wv.w, s);
-        }
-      }
-    }
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    if (i < RT && part == 0 && u0 + i < p.T) p.pcm[(long)b * p.pcm_stride + u0 + i] = s + p.bf;
-  }
 }
 
-template <int C, int RC, bool FINAL, int NW>
+template <int C, int RC, int NW>
 int launch_res(const ResDev& d, int batch, hipStream_t st) {
-  using K = ResCfg<C, RC, FINAL, NW>;
+  using K = ResCfg<C, RC, NW>;
   static bool attr_set = false;
   if (!attr_set) {  // > 64 KB of dynamic LDS must be requested once per kernel
-    ST_CHECK_HIP(hipFuncSetAttribute((const void*)resblock_kernel<C, RC, FINAL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS));
+    ST_CHECK_HIP(hipFuncSetAttribute((const void*)resblock_kernel<C, RC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS));
     attr_set = true;
   }
   const dim3 grid((d.T + K::RT - 1) / K::RT, batch);
   ST_REQUIRE(grid.y <= 65535, SMOLTTS_E_INVALID, "resblock: batch too large");
-  hipLaunchKernelGGL((resblock_kernel<C, RC, FINAL, NW>), grid, dim3(NW * 64), K::LDS, st, d);
+  hipLaunchKernelGGL((resblock_kernel<C, RC, NW>), grid, dim3(NW * 64), K::LDS, st, d);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
 }
@@ -295,18 +261,10 @@ int launch_res(const ResDev& d, int batch, hipStream_t st) {
 }  // namespace
 
 int launch_seanet_resblock(const MimiResblockArgs& a, hipStream_t st) {
-  ST_REQUIRE(a.x && a.w2 && a.b2 && a.w3 && a.b3 && a.T > 0 && a.batch > 0, SMOLTTS_E_INVALID, "resblock: null or empty argument");
-  ResDev d{a.x, (long)a.x_bstride, a.T, (const char*)a.w2, a.b2, (const char*)a.w3, a.b3, a.out, (long)a.o_bstride,
-           a.final_w, a.final_b, a.pcm, (long)a.pcm_stride, a.slot_pos};
-  if (a.channels == 128 && !a.final_conv) {
-    ST_REQUIRE(a.out, SMOLTTS_E_INVALID, "resblock: null output");
-    return launch_res<128, 32, false, 8>(d, a.batch, st);
-  }
-  if (a.channels == 64 && a.final_conv) {
-    ST_REQUIRE(a.final_w && a.pcm && a.slot_pos, SMOLTTS_E_INVALID, "resblock: the last stage needs the output conv, pcm and slot positions");
-    return launch_res<64, 32, true, 4>(d, a.batch, st);
-  }
-  set_error("resblock: no instance for %d channels, final_conv=%d", a.channels, a.final_conv);
+  ST_REQUIRE(a.x && a.w2 && a.b2 && a.w3 && a.b3 && a.out && a.T > 0 && a.batch > 0, SMOLTTS_E_INVALID, "resblock: null or empty argument");
+  ResDev d{a.x, (long)a.x_bstride, a.T, (const char*)a.w2, a.b2, (const char*)a.w3, a.b3, a.out, (long)a.o_bstride};
+  if (a.channels == 128) return launch_res<128, 32, 8>(d, a.batch, st);
+  set_error("resblock: no instance for %d channels", a.channels);
   return SMOLTTS_E_INVALID;
 }
 
