@@ -45,6 +45,14 @@ __device__ __forceinline__ long row_off(int m, int rpb, long ld, long bstride) {
   return (long)b * bstride + (long)(m - b * rpb) * ld;
 }
 
+// Workgroup barrier that orders LDS traffic only: global loads already in flight (register prefetches of the next weight group
+// / tile) stay in flight across it -- __syncthreads() is a full fence and drains them (s_waitcnt vmcnt(0)).
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
 __device__ __forceinline__ float silu1(float x) { return x / (1.f + expf(-x)); }
 __device__ __forceinline__ float gelu1(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
