@@ -27,6 +27,8 @@ struct AttnDev {
   float* out;
   char* out_x3;
   int n_q_heads, n_kv_heads, cache_len, window, score_cap;
+  int iota_pos;  // >= 0 (short-cache kernel): every row r is at this position of slot r -- the depth transformer's steps; no
+                 // row_pos / row_slot round trip in front of the cache loads
 };
 
 // 4 consecutive cache elements starting at element index e: fp32 (16 B) or bf16 (8 B, widened exactly)
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(256) void attn_short_kernel(AttnDev p, int n_pairs)
   const int pair = blockIdx.x * 4 + wave;
   if (pair >= n_pairs) return;
   const int row = pair / p.n_kv_heads, h = pair - row * p.n_kv_heads;
-  const int pos = p.row_pos[row], slot = p.row_slot[row];
+  const int pos = p.iota_pos >= 0 ? p.iota_pos : p.row_pos[row], slot = p.iota_pos >= 0 ? row : p.row_slot[row];
   const int HD = p.n_q_heads * 64;
   const bool ok = pos >= 0 && pos < p.cache_len;
   const int j_lo = (ok && p.window > 0 && pos + 1 > p.window) ? pos + 1 - p.window : 0;
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(256) void attn_short_kernel(AttnDev p, int n_pairs)
 
 int launch_attention(const float* q, const void* kc, const void* vc, const int32_t* row_pos, const int32_t* row_slot,
                      int n_rows, int n_q_heads, int n_kv_heads, int cache_len, int window, float* out, void* out_x3,
-                     hipStream_t stream, int kv_format) {
+                     hipStream_t stream, int kv_format, int iota_pos) {
   ST_REQUIRE(kv_format == SMOLTTS_KV_F32 || (kv_format == SMOLTTS_KV_BF16 && cache_len > 16), SMOLTTS_E_INVALID,
              "attention: kv_format %d unsupported here (bf16 caches need more than 16 entries)", kv_format);
   const bool kb = kv_format == SMOLTTS_KV_BF16;
@@ -422,7 +424,8 @@ int launch_attention(const float* q, const void* kc, const void* vc, const int32
   ST_REQUIRE(n_rows > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0 && cache_len > 0, SMOLTTS_E_INVALID,
              "attention: bad shape rows=%d q_heads=%d kv_heads=%d cache_len=%d", n_rows, n_q_heads, n_kv_heads, cache_len);
   const int G = n_q_heads / n_kv_heads;
-  AttnDev d{q, kc, vc, row_pos, row_slot, out, (char*)out_x3, n_q_heads, n_kv_heads, cache_len, window, 0};
+  AttnDev d{q, kc, vc, row_pos, row_slot, out, (char*)out_x3, n_q_heads, n_kv_heads, cache_len, window, 0, -1};
+  if (iota_pos >= 0 && cache_len <= 16) d.iota_pos = iota_pos;  // (only the short-cache kernel takes it)
   d.score_cap = (window > 0 && window < cache_len) ? window : cache_len;
   d.score_cap = (d.score_cap + 3) & ~3;
   // few workgroups (decode: rows x kv heads ~ 128): spread each cache over 16 waves; many rows

@@ -74,7 +74,7 @@ int launch_x3_pack(const float* x, int64_t ldx, int n_rows, int dim, void* x3a, 
 int launch_attention(const float* q, const void* kc, const void* vc, const int32_t* row_pos,
                      const int32_t* row_slot, int n_rows, int n_q_heads, int n_kv_heads,
                      int cache_len, int window, float* out, void* out_x3, hipStream_t stream,
-                     int kv_format = SMOLTTS_KV_F32);
+                     int kv_format = SMOLTTS_KV_F32, int iota_pos = -1);  // iota_pos >= 0 (caches <= 16): row r = slot r at that position
 int launch_embed(const int32_t* cols, int n_rows, int n_code_rows, const void* text_emb,
                  const void* cb_emb, int dim, int codebook_size, int cb_first_offset, int mask_mode,
                  int sem_start, int sem_end, int text_rows, int cb_rows, float* x, const EmitArgs* emit,

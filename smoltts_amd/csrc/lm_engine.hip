@@ -259,7 +259,8 @@ int launch_gemm3_m(const SmolttsSession* s, const SmolttsGemm3Args& a, hipStream
 int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, int n_head, int n_kv, int inter, float* x,
               float* q, int M, const int* row_pos, const int* row_slot, const float* rope, void* kc, void* vc,
               int cache_len, const char* in_x3, const EmitArgs& next, hipStream_t st, bool first_pos = false,
-              int kv_format = SMOLTTS_KV_F32) {
+              int kv_format = SMOLTTS_KV_F32, int iota_pos = -1) {
+  // iota_pos >= 0: row r is slot r at that position (the depth steps): the attention kernel needs no row_pos / row_slot loads
   // first_pos: every row is at position 0 (depth step 0), so attention over its single key is the row's own V: the QKV
   // epilogue publishes V as wo's operand and the attention launch is skipped.
   const SmolttsEngine* e = s->e;
@@ -277,7 +278,7 @@ int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, i
   if (!first_pos) {
     const int reps = dup_hit(s, cache_len <= 16 ? 100 : 101, 0) ? 2 : 1;
     for (int i = 0; i < reps; ++i)
-      ST_TRY(launch_attention(q, kc, vc, row_pos, row_slot, M, n_head, n_kv, cache_len, 0, nullptr, s->x3a, st, kv_format));
+      ST_TRY(launch_attention(q, kc, vc, row_pos, row_slot, M, n_head, n_kv, cache_len, 0, nullptr, s->x3a, st, kv_format, iota_pos));
   }
   {  // x += attn . Wo^T ; publish x * ffn_norm for w1|w3
     SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.wo, s->x3a, M, dim, dim, SMOLTTS_EPI_RESID);
@@ -375,7 +376,8 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
                           nullptr, nullptr, s->ssq};
       ST_TRY(run_block(s, e->w.fast_layers[l], c.fast_dim, c.fast_n_head, c.fast_n_kv_head, c.fast_inter, xf, s->qt, B,
                        s->fastpos + (size_t)i * B, s->iota, (const float*)(A + e->w.fast_rope), s->fkc + l * fl_stride,
-                       s->fvc + l * fl_stride, c.n_fast, (i == 0 && l == 0) ? first_x3 : s->x3n, next, st, /*first_pos=*/i == 0));
+                       s->fvc + l * fl_stride, c.n_fast, (i == 0 && l == 0) ? first_x3 : s->x3n, next, st, /*first_pos=*/i == 0,
+                       SMOLTTS_KV_F32, /*iota_pos=*/i));
     }
     {  // fast_norm + depthwise head slice i  (lm/rq_transformer.py:209-217)
       const size_t wrow = (size_t)i * e->w.fast_head_step_stride;  // rows; a row tile is 16 rows

@@ -79,14 +79,34 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int n_
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* row = logits + (long)r * ld;
   Top2 t{-INFINITY, 0x7fffffff, -INFINITY};
-  for (int j = tid; j < n_cols; j += 256) {
-    const float v = row[j];
-    if (v > t.v1) {  // strictly greater keeps the earliest index inside a thread (j ascending)
-      t.v2 = t.v1; t.v1 = v; t.i1 = j;
-    } else if (v > t.v2) {
-      t.v2 = v;
-    }
+#define ST_TAKE(V, J)                                                                               \
+  {                                                                                                 \
+    const float v_ = (V);                                                                           \
+    if (v_ > t.v1) { /* strictly greater keeps the earliest index inside a thread (j ascending) */ \
+      t.v2 = t.v1; t.v1 = v_; t.i1 = (J);                                                           \
+    } else if (v_ > t.v2) {                                                                         \
+      t.v2 = v_;                                                                                    \
+    }                                                                                               \
   }
+  // the whole row in one round trip: up to 8 float4 per thread, all requested before the first compare (a scalar loop is a
+  // chain of n_cols / 256 dependent L2 latencies: 8 for a 2048-entry codebook); kept for the sampling pass
+  const bool vec = (n_cols & 3) == 0 && (ld & 3) == 0 && n_cols <= 8 * 1024;
+  float4 v[8];
+  if (vec) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = tid * 4 + i * 1024;
+      v[i] = j < n_cols ? *reinterpret_cast<const float4*>(row + j) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = tid * 4 + i * 1024;
+      if (j < n_cols) { ST_TAKE(v[i].x, j) ST_TAKE(v[i].y, j + 1) ST_TAKE(v[i].z, j + 2) ST_TAKE(v[i].w, j + 3) }
+    }
+  } else {
+    for (int j = tid; j < n_cols; j += 256) ST_TAKE(row[j], j)
+  }
+#undef ST_TAKE
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     Top2 b;
@@ -102,14 +122,25 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int n_
     const float inv_t = 1.0f / sa.temp;
     const float cut = sa.min_p > 0.f ? logf(sa.min_p) : -INFINITY;
     Top2 k{-INFINITY, 0x7fffffff, -INFINITY};
-    for (int j = tid; j < n_cols; j += 256) {
-      const float z = (row[j] - a.v1) * inv_t;  // <= 0
-      if (z >= cut) {
-        const float u = uniform01(seed, r, frame, sa.step, j);
-        const float key = z - logf(-logf(u));
-        if (key > k.v1) { k.v1 = key; k.i1 = j; }
+#define ST_KEY(V, J)                                                  \
+  {                                                                   \
+    const float z = ((V) - a.v1) * inv_t; /* <= 0 */                  \
+    if (z >= cut) {                                                   \
+      const float u = uniform01(seed, r, frame, sa.step, (J));        \
+      const float key = z - logf(-logf(u));                           \
+      if (key > k.v1) { k.v1 = key; k.i1 = (J); }                     \
+    }                                                                 \
+  }
+    if (vec) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int j = tid * 4 + i * 1024;
+        if (j < n_cols) { ST_KEY(v[i].x, j) ST_KEY(v[i].y, j + 1) ST_KEY(v[i].z, j + 2) ST_KEY(v[i].w, j + 3) }
       }
+    } else {
+      for (int j = tid; j < n_cols; j += 256) ST_KEY(row[j], j)
     }
+#undef ST_KEY
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       Top2 b;
