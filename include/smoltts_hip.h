@@ -350,7 +350,7 @@ typedef struct SmolttsGemmArgs {
   float* v_cache_dev;
   int32_t n_q_heads, n_kv_heads, cache_len;
   const void* w3_dev;         /* optional, fp32 weights only: the same matrix as "W3" tiles; many-row calls (M >= 256, N >= 64,
-                                 no prologue) then run on the bf16 matrix cores with split operands (fp32-grade results) */
+                                 no prologue or the ELU one) then run on the bf16 matrix cores with split operands (fp32-grade results) */
   float* splitk_ws_dev;       /* optional, with w3_dev: workspace for split-K partial sums (long K over few tiles) ... */
   int64_t splitk_ws_floats;   /* ... and its size in floats (4 * M * N needed; smaller = no split) */
 } SmolttsGemmArgs;

@@ -73,6 +73,42 @@ def test_b3_split_k_is_deterministic_and_matches_float64(E, ops, M, N, K):
     assert torch.equal(small, one)
 
 
+def test_b3_elu_prologue_and_residual(E, ops):
+    """First conv of a resnet block on the raw tensor: ELU on the way in (hardware exponential: ~6e-8 absolute), + residual out."""
+    g = torch.Generator().manual_seed(11)
+    M, K, N = 4096, 256, 128
+    x, w = torch.randn(M, K, generator=g) * 2, torch.randn(N, K, generator=g) / math.sqrt(K)
+    res = torch.randn(M, N, generator=g)
+    w32, w3 = ops.pack_weight(w, fp32=True), ops.pack_weight_w3(w)
+    ref = res.double() + F.elu(x.double()) @ w.double().T
+    got = ops.linear(x.cuda(), w32, N, w_fp32=True, prologue=E.PRO_ELU, epilogue=E.EPI_RESID, resid=res.cuda(), w3=w3).cpu()
+    assert rel_err(got, ref) < 2e-6
+
+
+@pytest.mark.parametrize("taps,cin,N,T,B", [(3, 256, 128, 2203, 3), (2, 128, 320, 1301, 2), (7, 64, 64, 3101, 4)])
+def test_b3_conv_windows_over_halo_prefixed_slots(E, ops, taps, cin, N, T, B):
+    """Causal conv as a GEMM over overlapping windows (row stride = cin, K = taps * cin) of per-slot buffers with taps - 1 halo
+    rows: the kernel visits the taps of a channel slice back to back (a different K order than the fp32 kernel) -- same result."""
+    g = torch.Generator().manual_seed(taps * 1000 + cin)
+    rows = T + taps - 1
+    buf = torch.randn(B, rows, cin, generator=g)
+    w = torch.randn(N, taps * cin, generator=g) / math.sqrt(taps * cin)
+    b = torch.randn(N, generator=g)
+    win = torch.stack([buf[:, t:t + taps].reshape(B, taps * cin) for t in range(T)], dim=1)  # [B][T][taps * cin]
+    ref = win.double() @ w.double().T + b.double()
+    w32, w3 = ops.pack_weight(w, fp32=True), ops.pack_weight_w3(w)
+    out = torch.zeros(B, T, N, device="cuda")
+    kw = dict(w_fp32=True, bias=b.cuda(), out=out, M=B * T, K=taps * cin, ldx=cin, x_bstride=rows * cin, rows_per_batch=T, ldo=N, o_bstride=T * N)
+    ops.linear(buf.cuda(), w32, N, w3=w3, **kw)
+    got = out.cpu().clone()
+    out.zero_()
+    ops.linear(buf.cuda(), w32, N, **kw)
+    old = out.cpu()
+    assert not torch.equal(got, old)  # (the shapes are large enough for the bf16x3 kernel: a different summation order)
+    print(f"taps={taps} cin={cin}: bf16x3 {rel_err(got, ref):.2e}, fp32 MFMA {rel_err(old, ref):.2e}")
+    assert rel_err(got, ref) < 2e-6 and rel_err(got, ref) < 4 * rel_err(old, ref) + 2e-7
+
+
 def test_b3_epilogues(E, ops):
     g = torch.Generator().manual_seed(5)
     M, K, N = 1024, 512, 512
