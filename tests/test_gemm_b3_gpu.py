@@ -85,10 +85,12 @@ def test_b3_elu_prologue_and_residual(E, ops):
     assert rel_err(got, ref) < 2e-6
 
 
-@pytest.mark.parametrize("taps,cin,N,T,B", [(3, 256, 128, 2203, 3), (2, 128, 320, 1301, 2), (7, 64, 64, 3101, 4)])
+@pytest.mark.parametrize("taps,cin,N,T,B", [(3, 256, 128, 2203, 3), (2, 128, 320, 1301, 2), (7, 64, 64, 3101, 4),
+                                             (3, 256, 128, 5500, 3), (2, 256, 640, 3001, 6), (3, 128, 128, 1111, 16)])  # the last three: conv_xs.hip
 def test_b3_conv_windows_over_halo_prefixed_slots(E, ops, taps, cin, N, T, B):
     """Causal conv as a GEMM over overlapping windows (row stride = cin, K = taps * cin) of per-slot buffers with taps - 1 halo
-    rows: the kernel visits the taps of a channel slice back to back (a different K order than the fp32 kernel) -- same result."""
+    rows: the kernel visits the taps of a channel slice back to back (a different K order than the fp32 kernel) -- same result.
+    With <= 256 channels, N = 128 | 640 and >= 256 tiles of 64 rows the window-stationary kernel (conv_xs.hip) takes the call."""
     g = torch.Generator().manual_seed(taps * 1000 + cin)
     rows = T + taps - 1
     buf = torch.randn(B, rows, cin, generator=g)
