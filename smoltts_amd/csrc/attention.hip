@@ -193,14 +193,26 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
 // so no value ever crosses lanes except the row maximum (two shuffles per tile and head).  Rows of a tile may belong to
 // different slots (utterance boundaries in the packed prompt): one pass per distinct slot, the other rows masked.
 template <int G, bool KB>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnDev p, int n_rows) {
+__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnDev p, int n_rows, int nx) {  // nx = row tiles
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = lane & 15, q = lane >> 4;
   // G = query heads per wave (consecutive heads of one kv group): blockIdx.y counts groups of G query heads
   // The workgroup's 4 waves share the 16 rows and take every 4th key tile each (a causal row tile late in a long prompt
   // has many: the critical path of the launch); their (max, sum, O) partials are merged through LDS in fixed order.
   __shared__ float merge[4][64][G * 18];
-  const int hq0 = blockIdx.y * G, kvh = hq0 / (p.n_q_heads / p.n_kv_heads), row0 = blockIdx.x * 16;
+  // XCD-aware order (1-D grid; ids are dealt round-robin over the 8 XCDs, each with its own L2): the workgroups that read the
+  // same K / V -- 4 neighbouring row tiles (one slot's rows of a codec chunk, a stretch of one prompt) x the query-head groups
+  // of one kv head -- form a unit, and a unit's members get consecutive slots on ONE XCD.  With the plain 2-D grid the 4 row
+  // tiles of a slot landed on 4 XCDs and each fetched the slot's K / V for itself (rocprofv3 FETCH_SIZE of the codec
+  // transformer's attention: 1.0 GB per 1024-frame chunk against 0.3 GB of K / V).
+  const int gq = p.n_q_heads / (p.n_kv_heads * G);          // head groups per kv head
+  const int members = 4 * gq, nxg = (nx + 3) >> 2, units = nxg * p.n_kv_heads;
+  const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+  const int mem = k % members, u = (k / members) * 8 + xcd;
+  if (u >= units) return;  // (the grid is padded to whole groups of 8 units; uniform over the workgroup)
+  const int kvh = u % p.n_kv_heads, bx = (u / p.n_kv_heads) * 4 + mem / gq;
+  if (bx >= nx) return;
+  const int hq0 = (kvh * gq + mem % gq) * G, row0 = bx * 16;
   const int HD = p.n_q_heads * 64, row = row0 + r;
   const bool in_range = row < n_rows;
   const int pos = in_range ? p.row_pos[row] : -1;
@@ -459,8 +471,10 @@ int launch_attention(const float* q, const void* kc, const void* vc, const int32
   if ((long)n_rows * n_kv_heads >= 1024 && getenv("SMOLTTS_NO_MFMA_ATTN") == nullptr) {  // prompt prefill, codec transformer
     // one query head per wave: the longest row tile (the critical path of the launch) is G times shorter, and the K / V
     // tiles re-read by the G waves of a kv group come from L2
-    if (kb) hipLaunchKernelGGL((attn_prefill_kernel<1, true>), dim3((n_rows + 15) / 16, n_q_heads), dim3(256), 0, stream, d, n_rows);
-    else hipLaunchKernelGGL((attn_prefill_kernel<1, false>), dim3((n_rows + 15) / 16, n_q_heads), dim3(256), 0, stream, d, n_rows);
+    const int nx = (n_rows + 15) / 16, units = ((nx + 3) / 4) * n_kv_heads, members = 4 * (n_q_heads / n_kv_heads);
+    const dim3 pgrid((unsigned)(((units + 7) / 8) * 8 * members));
+    if (kb) hipLaunchKernelGGL((attn_prefill_kernel<1, true>), pgrid, dim3(256), 0, stream, d, n_rows, nx);
+    else hipLaunchKernelGGL((attn_prefill_kernel<1, false>), pgrid, dim3(256), 0, stream, d, n_rows, nx);
     ST_CHECK_HIP(hipGetLastError());
     return SMOLTTS_OK;
   }

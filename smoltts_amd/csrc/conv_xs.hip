@@ -12,6 +12,10 @@
 // N / 16 column tiles for all four row tiles and streams its W3 fragments from L2 straight into registers, one chunk ahead
 // (each fragment is used by exactly one wave of the workgroup), and the K loop has no barrier at all.
 // LDS: 3 pieces x C_in / 8 groups x 80 rows x 16 B = 120 KB at C_in = 256: one 8-wave workgroup per CU.
+//
+// The same kernel with one "tap" is a plain Linear over rows of K <= 512 values (the decoder transformer's wqkv, wo and fc1 at
+// M = 2048: transformer.py:34-96): tiles of 32 rows (96 KB of pieces), the N / 16 column tiles split over 4 workgroups per row
+// tile so that 256 workgroups fill the chip; epilogues of gemm_dev.h (RoPE + q / KV scatter, layer scale + residual, GELU).
 #include <stdlib.h>
 
 #include "gemm_dev.h"
@@ -20,19 +24,22 @@ namespace smoltts {
 
 namespace {
 
-constexpr int XS_S = 64, XS_MT = 4, XS_RA = 80;  // output rows per tile, 16-row tiles, LDS rows per plane (>= S + taps - 1; % 16 == 0)
-constexpr int XS_MAX_CIN = 256;
+constexpr int XS_RA_CONV = 80;  // conv: 64 output rows per tile; LDS rows per plane >= 64 + taps - 1, % 16 == 0
+constexpr int XS_MAX_CIN = 256, XS_MAX_K_LINEAR = 512;
 
 __device__ __forceinline__ float elu_hw_xs(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
 
-template <int NTW>
+// MT 16-row tiles of output rows per workgroup, NTW column tiles per wave, RA LDS rows per plane, EPI the epilogue (gemm_dev.h)
+template <int NTW, int MT, int RA, int EPI>
 __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
+  constexpr int XS_S = 16 * MT, XS_MT = MT, XS_RA = RA;
   extern __shared__ __attribute__((aligned(16))) uint4 xp[];  // [piece][C_in / 8 groups = (chunk, q)][XS_RA rows]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  const int b = blockIdx.y, row0 = blockIdx.x * XS_S, T = p.rows_per_batch;
-  const int G = (int)(p.ldx >> 3), nrows = XS_S + p.taps - 1, nchunks = p.K >> 5;
+  const int b = blockIdx.y, row0 = blockIdx.x * XS_S, T = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
+  const int G = p.cpt * 4, nrows = XS_S + p.taps - 1, nchunks = p.K >> 5;  // G 8-value groups per window row
+  const int nt0 = (int)blockIdx.z * 8 * NTW + wave * NTW;                   // the wave's first column tile
   const float* xb = p.x + (long)b * p.x_bstride + (long)row0 * p.ldx;
 
   // ---- the tile's window rows -> pieces; 8 consecutive lanes take 8 consecutive rows of one 8-channel group (128 contiguous
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
     for (int t = 0; t < NTW; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // W3 tile (column tile nt, chunk kc) at (nt * nchunks + kc) * 3072: the wave's tiles are NTW * nchunks consecutive tiles
-  const char* wtile = p.w3 + (size_t)(wave * NTW) * nchunks * 3072;
+  const char* wtile = p.w3 + (size_t)nt0 * nchunks * 3072;
   const int wlane = lane * 16;
   uint4 wq[2][NTW][3];
 #pragma unroll
@@ -105,49 +112,75 @@ __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
     const int rl = row0 + mt * 16 + r;
     if (rl >= T) continue;
     const int m = b * T + rl;
-    const long orow = row_off(m, T, p.ldo, p.o_bstride);
+    const long orow = row_off(m, p.rows_per_batch, p.ldo, p.o_bstride);
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
       float v[4] = {acc[mt][t][0], acc[mt][t][1], acc[mt][t][2], acc[mt][t][3]};
-      rows_epilogue<SMOLTTS_EPI_STORE>(p, m, orow, (wave * NTW + t) * 16 + q * 4, v);
+      rows_epilogue<EPI>(p, m, orow, (nt0 + t) * 16 + q * 4, v);
     }
   }
 }
 
-template <int NTW>
-int launch_xs(const GemmDev& g, hipStream_t stream) {
-  const size_t lds = (size_t)3 * (g.ldx >> 3) * XS_RA * 16;
+template <int NTW, int MT, int RA, int EPI>
+int launch_xs(const GemmDev& g, int nsplit, hipStream_t stream) {
+  const size_t lds = (size_t)3 * (g.cpt * 4) * RA * 16;
   static size_t attr = 0;
   if (lds > attr) {  // > 64 KB of dynamic LDS must be requested per kernel
-    ST_CHECK_HIP(hipFuncSetAttribute((const void*)conv_xs_kernel<NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ST_CHECK_HIP(hipFuncSetAttribute((const void*)conv_xs_kernel<NTW, MT, RA, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = lds;
   }
-  const dim3 grid((g.rows_per_batch + XS_S - 1) / XS_S, g.M / g.rows_per_batch);
-  hipLaunchKernelGGL((conv_xs_kernel<NTW>), grid, dim3(512), lds, stream, g);
+  const int T = g.rows_per_batch > 0 ? g.rows_per_batch : g.M;
+  const dim3 grid((T + 16 * MT - 1) / (16 * MT), g.M / T, nsplit);
+  hipLaunchKernelGGL((conv_xs_kernel<NTW, MT, RA, EPI>), grid, dim3(512), lds, stream, g);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
 }
 
+// Linear shapes: (N, epilogue) -> column tiles per wave at 4 workgroups per row tile
+int linear_ntw(const GemmDev& d, int epilogue) {
+  if (epilogue == SMOLTTS_EPI_QKV_ROPE && d.N == 1536) return 3;
+  if (epilogue == SMOLTTS_EPI_SCALE_RESID && d.N == 512) return 1;
+  if (epilogue == SMOLTTS_EPI_GELU && d.N == 2048) return 4;
+  return 0;
+}
+
 }  // namespace
 
-// Shapes the kernel takes: plain store epilogue, a conv window (K = taps * ldx over overlapping rows) of at most 256 channels,
-// N = 128 or 640 (one or five column tiles per wave), whole slots, and enough tiles for the chip.
+// Shapes the kernel takes.  Conv windows (K = taps * ldx over overlapping rows) of at most 256 channels: plain store epilogue,
+// N = 128 or 640 (one or five column tiles per wave), whole slots, enough tiles for the chip.  Linears of K <= 512 over many
+// rows: the decoder transformer's wqkv (N = 1536, RoPE / cache scatter: 32 -> 26 us at M = 2048), wo (N = 512, layer scale +
+// residual: 20.6 -> 13.4 us) and fc1 (N = 2048, GELU: 38 -> 33 us).
 bool conv_xs_applies(const GemmDev& d, int epilogue) {
   static const bool off = [] { const char* e = getenv("SMOLTTS_CONV_XS"); return e && atoi(e) == 0; }();  // experiments
-  if (off || epilogue != SMOLTTS_EPI_STORE || !d.w3 || d.rows_per_batch <= 0 || d.M % d.rows_per_batch != 0) return false;
-  if (d.ldx >= d.K || d.ldx % 32 != 0 || d.ldx > XS_MAX_CIN || d.K % d.ldx != 0) return false;
+  static const bool lin_off = [] { const char* e = getenv("SMOLTTS_LINEAR_XS"); return e && atoi(e) == 0; }();
+  if (off || !d.w3) return false;
+  if (d.x_bstride % 4 != 0 || d.ldo % 4 != 0 || d.o_bstride % 4 != 0 || d.ldx % 4 != 0) return false;
+  if (d.ldx >= d.K) {  // Linear
+    if (lin_off || d.rows_per_batch > 0 || d.pro_elu || d.K > XS_MAX_K_LINEAR || d.K % 32 != 0 || linear_ntw(d, epilogue) == 0) return false;
+    return (long)((d.M + 31) / 32) * 4 >= 256;
+  }
+  if (epilogue != SMOLTTS_EPI_STORE || d.rows_per_batch <= 0 || d.M % d.rows_per_batch != 0) return false;
+  if (d.ldx % 32 != 0 || d.ldx > XS_MAX_CIN || d.K % d.ldx != 0) return false;
   const int taps = (int)(d.K / d.ldx);
-  if (taps < 2 || XS_S + taps - 1 > XS_RA || (d.N != 128 && d.N != 640)) return false;
-  if (d.x_bstride % 4 != 0 || d.ldo % 4 != 0 || d.o_bstride % 4 != 0) return false;
-  const long tiles = (long)((d.rows_per_batch + XS_S - 1) / XS_S) * (d.M / d.rows_per_batch);
+  if (taps < 2 || 64 + taps - 1 > XS_RA_CONV || (d.N != 128 && d.N != 640)) return false;
+  const long tiles = (long)((d.rows_per_batch + 63) / 64) * (d.M / d.rows_per_batch);
   return tiles >= 256 && d.M / d.rows_per_batch <= 65535;
 }
 
-int launch_conv_xs(const GemmDev& d, hipStream_t stream) {
+int launch_conv_xs(const GemmDev& d, int epilogue, hipStream_t stream) {
   GemmDev g = d;
+  if (d.ldx >= d.K) {  // Linear: one "tap" of K values
+    g.taps = 1;
+    g.cpt = d.K >> 5;
+    switch (linear_ntw(d, epilogue)) {
+      case 3: return launch_xs<3, 2, 32, SMOLTTS_EPI_QKV_ROPE>(g, 4, stream);
+      case 1: return launch_xs<1, 2, 32, SMOLTTS_EPI_SCALE_RESID>(g, 4, stream);
+      default: return launch_xs<4, 2, 32, SMOLTTS_EPI_GELU>(g, 4, stream);
+    }
+  }
   g.taps = (int)(d.K / d.ldx);
   g.cpt = (int)(d.ldx >> 5);
-  return d.N == 640 ? launch_xs<5>(g, stream) : launch_xs<1>(g, stream);
+  return d.N == 640 ? launch_xs<5, 4, XS_RA_CONV, SMOLTTS_EPI_STORE>(g, 1, stream) : launch_xs<1, 4, XS_RA_CONV, SMOLTTS_EPI_STORE>(g, 1, stream);
 }
 
 }  // namespace smoltts

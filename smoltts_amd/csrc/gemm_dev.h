@@ -133,7 +133,7 @@ __device__ __forceinline__ f32x4 mfma_b3(const uint4 w[3], const uint4 x[3], f32
 
 int launch_gemm_b3(const GemmDev& d, int epilogue, hipStream_t stream);  // gemm_b3.hip
 bool gemm_b3_applies(int M, int N, int K, int epilogue);
-int launch_conv_xs(const GemmDev& d, hipStream_t stream);    // conv_xs.hip: conv windows of <= 256 channels, X stationary in LDS
+int launch_conv_xs(const GemmDev& d, int epilogue, hipStream_t stream);  // conv_xs.hip: conv windows of <= 256 channels / Linears of K <= 512, X stationary in LDS
 bool conv_xs_applies(const GemmDev& d, int epilogue);
 
 }  // namespace smoltts

@@ -111,6 +111,28 @@ def test_b3_conv_windows_over_halo_prefixed_slots(E, ops, taps, cin, N, T, B):
     assert rel_err(got, ref) < 2e-6 and rel_err(got, ref) < 4 * rel_err(old, ref) + 2e-7
 
 
+@pytest.mark.parametrize("M", [2048, 2333])
+def test_transformer_linears_at_chunk_size(E, ops, M):
+    """wo (layer scale + residual, N = 512) and fc1 (GELU, N = 2048) of the decoder transformer at the row count of a 32 x 32
+    chunk: the row-stationary kernel (conv_xs.hip, Linear mode) against float64."""
+    g = torch.Generator().manual_seed(31 + M)
+    K = 512
+    x = torch.randn(M, K, generator=g)
+    for N, epi in ((512, E.EPI_SCALE_RESID), (2048, E.EPI_GELU)):
+        w = torch.randn(N, K, generator=g) / math.sqrt(K)
+        b, res, sc = torch.randn(N, generator=g), torch.randn(M, N, generator=g), torch.randn(N, generator=g)
+        w32, w3 = ops.pack_weight(w, fp32=True), ops.pack_weight_w3(w)
+        y = x.double() @ w.double().T + b.double()
+        ref = res.double() + sc.double() * y if epi == E.EPI_SCALE_RESID else F.gelu(y)
+        kw = dict(w_fp32=True, epilogue=epi, bias=b.cuda())
+        if epi == E.EPI_SCALE_RESID:
+            kw.update(scale=sc.cuda(), resid=res.cuda())
+        got = ops.linear(x.cuda(), w32, N, w3=w3, **kw).cpu()
+        old = ops.linear(x.cuda(), w32, N, **kw).cpu()
+        assert not torch.equal(got, old)
+        assert rel_err(got, ref) < 2e-6 and rel_err(got, ref) < 4 * rel_err(old, ref) + 2e-7
+
+
 def test_b3_epilogues(E, ops):
     g = torch.Generator().manual_seed(5)
     M, K, N = 1024, 512, 512
@@ -129,14 +151,15 @@ def test_b3_epilogues(E, ops):
     assert rel_err(raw.cpu(), y) < 3e-6 and rel_err(got, F.elu(y)) < 3e-6
 
 
-def test_b3_qkv_rope_equals_the_fp32_kernel_layout(E, ops):
+@pytest.mark.parametrize("M", [600, 2048, 2101])  # >= 2048 rows: the row-stationary kernel (conv_xs.hip, Linear mode)
+def test_b3_qkv_rope_equals_the_fp32_kernel_layout(E, ops, M):
     """Same epilogue code as the fp32 many-row kernel: q rows, K/V cache scatter, interleaved-pair rotation."""
     g = torch.Generator().manual_seed(8)
-    M, K, H = 600, 512, 8
+    K, H = 512, 8
     N = 3 * H * 64
     x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
     w32, w3 = ops.pack_weight(w, fp32=True), ops.pack_weight_w3(w)
-    slots, cache_len = 3, 256
+    slots, cache_len = 9, 256
     pairs = torch.randperm(slots * cache_len, generator=g)[:M]
     row_slot, row_pos = (pairs // cache_len).int().cuda(), (pairs % cache_len).int().cuda()
     ang = torch.outer(torch.arange(cache_len).float(), 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64)))
