@@ -136,8 +136,13 @@ int launch_xs(const GemmDev& g, int nsplit, hipStream_t stream) {
   return SMOLTTS_OK;
 }
 
-// Linear shapes: (N, epilogue) -> column tiles per wave at 4 workgroups per row tile
+// Linear shapes: (N, epilogue) -> column tiles per wave.  The transformer's Linears (one flat row range): 32-row tiles, the
+// column tiles split over 4 workgroups; the k1 convs that end a resnet block (per-slot rows, + residual): 64-row tiles, all columns.
 int linear_ntw(const GemmDev& d, int epilogue) {
+  if (d.rows_per_batch > 0) {
+    if (epilogue == SMOLTTS_EPI_RESID && d.K <= 256 && (d.N == 256 || d.N == 512)) return d.N / 128;
+    return 0;
+  }
   if (epilogue == SMOLTTS_EPI_QKV_ROPE && d.N == 1536) return 3;
   if (epilogue == SMOLTTS_EPI_SCALE_RESID && d.N == 512) return 1;
   if (epilogue == SMOLTTS_EPI_GELU && d.N == 2048) return 4;
@@ -149,14 +154,17 @@ int linear_ntw(const GemmDev& d, int epilogue) {
 // Shapes the kernel takes.  Conv windows (K = taps * ldx over overlapping rows) of at most 256 channels: plain store epilogue,
 // N = 128 or 640 (one or five column tiles per wave), whole slots, enough tiles for the chip.  Linears of K <= 512 over many
 // rows: the decoder transformer's wqkv (N = 1536, RoPE / cache scatter: 32 -> 26 us at M = 2048), wo (N = 512, layer scale +
-// residual: 20.6 -> 13.4 us) and fc1 (N = 2048, GELU: 38 -> 33 us).
+// residual: 20.6 -> 13.4 us) and fc1 (N = 2048, GELU: 38 -> 33 us); the k1 convs that end the resnet blocks of stages 1 and 2
+// (K = 256 / 128 -> N = 512 / 256, + residual, per-slot rows).
 bool conv_xs_applies(const GemmDev& d, int epilogue) {
   static const bool off = [] { const char* e = getenv("SMOLTTS_CONV_XS"); return e && atoi(e) == 0; }();  // experiments
   static const bool lin_off = [] { const char* e = getenv("SMOLTTS_LINEAR_XS"); return e && atoi(e) == 0; }();
   if (off || !d.w3) return false;
   if (d.x_bstride % 4 != 0 || d.ldo % 4 != 0 || d.o_bstride % 4 != 0 || d.ldx % 4 != 0) return false;
   if (d.ldx >= d.K) {  // Linear
-    if (lin_off || d.rows_per_batch > 0 || d.pro_elu || d.K > XS_MAX_K_LINEAR || d.K % 32 != 0 || linear_ntw(d, epilogue) == 0) return false;
+    if (lin_off || d.pro_elu || d.K > XS_MAX_K_LINEAR || d.K % 32 != 0 || linear_ntw(d, epilogue) == 0) return false;
+    if (d.rows_per_batch > 0)
+      return d.M % d.rows_per_batch == 0 && d.M / d.rows_per_batch <= 65535 && (long)((d.rows_per_batch + 63) / 64) * (d.M / d.rows_per_batch) >= 256;
     return (long)((d.M + 31) / 32) * 4 >= 256;
   }
   if (epilogue != SMOLTTS_EPI_STORE || d.rows_per_batch <= 0 || d.M % d.rows_per_batch != 0) return false;
@@ -172,6 +180,8 @@ int launch_conv_xs(const GemmDev& d, int epilogue, hipStream_t stream) {
   if (d.ldx >= d.K) {  // Linear: one "tap" of K values
     g.taps = 1;
     g.cpt = d.K >> 5;
+    if (d.rows_per_batch > 0)
+      return d.N == 256 ? launch_xs<2, 4, 64, SMOLTTS_EPI_RESID>(g, 1, stream) : launch_xs<4, 4, 64, SMOLTTS_EPI_RESID>(g, 1, stream);
     switch (linear_ntw(d, epilogue)) {
       case 3: return launch_xs<3, 2, 32, SMOLTTS_EPI_QKV_ROPE>(g, 4, stream);
       case 1: return launch_xs<1, 2, 32, SMOLTTS_EPI_SCALE_RESID>(g, 4, stream);

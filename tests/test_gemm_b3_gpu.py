@@ -133,6 +133,29 @@ def test_transformer_linears_at_chunk_size(E, ops, M):
         assert rel_err(got, ref) < 2e-6 and rel_err(got, ref) < 4 * rel_err(old, ref) + 2e-7
 
 
+@pytest.mark.parametrize("K,N,T,B", [(128, 256, 1100, 15), (256, 512, 700, 24)])
+def test_k1_conv_plus_residual_over_slots(E, ops, K, N, T, B):
+    """The conv that ends a resnet block: k = 1 over per-slot rows, + the block input read with its own strides (it sits two halo
+    rows into a wider buffer), ELU on the way out -- conv_xs.hip in Linear mode with 64-row tiles."""
+    g = torch.Generator().manual_seed(K + N)
+    x = torch.randn(B, T, K, generator=g)
+    w, b = torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    resbuf = torch.randn(B, T + 2, N, generator=g)
+    ref = F.elu(resbuf[:, 2:].double() + x.double() @ w.double().T + b.double())
+    w32, w3 = ops.pack_weight(w, fp32=True), ops.pack_weight_w3(w)
+    out = torch.zeros(B, T, N, device="cuda")
+    rb = resbuf.cuda()
+    kw = dict(w_fp32=True, epilogue=E.EPI_RESID, bias=b.cuda(), resid=rb[:, 2:], ldr=N, r_bstride=(T + 2) * N, out=out, M=B * T, K=K,
+              ldx=K, x_bstride=T * K, rows_per_batch=T, ldo=N, o_bstride=T * N, elu_out=True)
+    ops.linear(x.cuda(), w32, N, w3=w3, **kw)
+    got = out.cpu().clone()
+    out.zero_()
+    ops.linear(x.cuda(), w32, N, **kw)
+    old = out.cpu()
+    assert not torch.equal(got, old)
+    assert rel_err(got, ref) < 2e-6 and rel_err(got, ref) < 4 * rel_err(old, ref) + 2e-7
+
+
 def test_b3_epilogues(E, ops):
     g = torch.Generator().manual_seed(5)
     M, K, N = 1024, 512, 512
