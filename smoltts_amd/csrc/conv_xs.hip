@@ -91,6 +91,7 @@ __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
         _Pragma("unroll") for (int pc = 0; pc < 3; ++pc)                                                                \
           wq[(BUF) ^ 1][t][pc] = *reinterpret_cast<const uint4*>(wtile + (size_t)(t * nchunks + (KC) + 1) * 3072 + pc * 1024 + wlane); \
     }                                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0); /* the loads go out HERE: left alone, the scheduler sinks them to the end of the chunk's MFMAs */ \
     _Pragma("unroll") for (int mt = 0; mt < XS_MT; ++mt) {                                                              \
       uint4 xf[3];                                                                                                      \
       _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) xf[pc] = xp[(pc * G + xc * 4 + q) * XS_RA + mt * 16 + r + tap];  \
