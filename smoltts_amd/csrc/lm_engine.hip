@@ -67,6 +67,7 @@ struct SmolttsSession {
   bool tail_ready;
   hipGraphExec_t multi_exec;   // `multi_frames` consecutive decode frames in one graph (fewer graph launches per tick / chunk)
   bool multi_ready;
+  int flight_limit;            // SMOLTTS_MAX_FRAMES_IN_FLIGHT as read at creation (0 = unbounded)
   int multi_frames;            // SMOLTTS_FRAMES_PER_GRAPH (1 = single-frame graphs only); default: the first multi-frame call's count, at most 8
   bool prefilled;
   // bounded run-ahead of the host over the GPU (smoltts_lm_decode): an event every `flight_group` frame graphs, the host
@@ -619,6 +620,7 @@ int smoltts_session_create_kv(SmolttsEngine* e, void* slab_dev, size_t slab_byte
     const char* fpg = getenv("SMOLTTS_FRAMES_PER_GRAPH");  // frames captured into one graph where that many remain to be launched
     s->multi_frames = fpg ? atoi(fpg) : 0;  // 0: chosen by the first call that asks for several frames (min(n, 8))
     if (s->multi_frames < 0 || s->multi_frames > 16) s->multi_frames = 1;
+    s->flight_limit = limit;
   }
   hipLaunchKernelGGL(init_state_kernel, dim3((max_batch + 63) / 64), dim3(64), 0, 0, max_batch, e->cfg.n_fast, s->iota,
                      s->fastpos, s->pos, s->frames, s->done, s->mask, s->margin, s->margin_at, s->cur_col, s->new_col, s->salt);
@@ -758,6 +760,8 @@ int smoltts_lm_decode(SmolttsSession* s, int32_t n_frames, void* stream) {
   // Frames are launched `multi_frames` at a time where that many remain: every graph launch costs the GPU a gap between the
   // last node of one graph and the first of the next (measured: the frame rate of a 32-frame chunk rises by the gaps saved).
   if (s->multi_frames == 0 && n_frames >= 2) s->multi_frames = n_frames < 8 ? n_frames : 8;  // a serving tick / a bench chunk
+  // (a graph of several frames is that many frames queued at once: it stays inside the run-ahead bound, see below)
+  if (s->flight_limit > 0 && s->multi_frames > s->flight_limit) s->multi_frames = s->flight_limit;
   const int mf = s->multi_frames;
   if (mf > 1 && n_frames >= mf && !s->multi_ready) {
     ST_TRY(capture_graph(st, &s->multi_exec, [&](hipStream_t cap) {
