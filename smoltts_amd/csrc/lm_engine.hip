@@ -613,12 +613,16 @@ int smoltts_session_create_kv(SmolttsEngine* e, void* slab_dev, size_t slab_byte
   }
   {  // frames the host may run ahead of the GPU: SMOLTTS_MAX_FRAMES_IN_FLIGHT (default 16; 0 = unbounded)
     const char* lim = getenv("SMOLTTS_MAX_FRAMES_IN_FLIGHT");
-    const int limit = lim ? atoi(lim) : 16;
+    // under `rocprofv3 --pmc` (it exports ROCPROF_COUNTERS to the profiled process) every dispatch becomes several packets of the
+    // profiler's intercept queue, which does not survive thousands of them queued at once: 2 frames ahead, one frame per graph
+    const char* pmc = getenv("ROCPROF_COUNTERS");
+    const bool counters = pmc && *pmc;
+    const int limit = lim ? atoi(lim) : (counters ? 2 : 16);
     s->flight_group = limit > 0 ? (limit + 1) / 2 : 0;
     for (int k = 0; k < 2; ++k)
       if (hipEventCreateWithFlags(&s->flight_ev[k], hipEventDisableTiming) != hipSuccess) s->flight_group = 0;
     const char* fpg = getenv("SMOLTTS_FRAMES_PER_GRAPH");  // frames captured into one graph where that many remain to be launched
-    s->multi_frames = fpg ? atoi(fpg) : 0;  // 0: chosen by the first call that asks for several frames (min(n, 8))
+    s->multi_frames = fpg ? atoi(fpg) : (counters ? 1 : 0);  // 0: chosen by the first call that asks for several frames (min(n, 8))
     if (s->multi_frames < 0 || s->multi_frames > 16) s->multi_frames = 1;
     s->flight_limit = limit;
   }
