@@ -310,7 +310,10 @@ int smoltts_mimi_encode(SmolttsMimiEncoder* e, const float* pcm_dev, int32_t n_s
 enum {  /* prologue applied to the activation operand */
   SMOLTTS_PRO_NONE = 0,
   SMOLTTS_PRO_RMSNORM = 1,  /* x * rsqrt(mean(x^2)+eps) * gamma */
-  SMOLTTS_PRO_ELU = 2
+  SMOLTTS_PRO_ELU = 2,
+  SMOLTTS_PRO_LAYERNORM = 3 /* fp32 weights: nn.LayerNorm over the K values of a row: gamma_dev = weight, beta_dev = bias, eps;
+                               fused into the GEMM where its kernel can (few rows; K = 512 at chunk size), otherwise applied by the
+                               stand-alone kernel into ln_scratch_dev [M][K] first */
 };
 enum {  /* epilogue */
   SMOLTTS_EPI_STORE = 0,        /* out = acc (+ bias) */
@@ -353,6 +356,8 @@ typedef struct SmolttsGemmArgs {
                                  no prologue or the ELU one) then run on the bf16 matrix cores with split operands (fp32-grade results) */
   float* splitk_ws_dev;       /* optional, with w3_dev: workspace for split-K partial sums (long K over few tiles) ... */
   int64_t splitk_ws_floats;   /* ... and its size in floats (4 * M * N needed; smaller = no split) */
+  const float* beta_dev;      /* PRO_LAYERNORM: bias [K] */
+  float* ln_scratch_dev;      /* PRO_LAYERNORM: [M][K] floats for the calls whose kernel has no such prologue */
 } SmolttsGemmArgs;
 
 int smoltts_k_gemm(const SmolttsGemmArgs* a, void* stream);

@@ -44,6 +44,69 @@ __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
 
   // ---- the tile's window rows -> pieces; 8 consecutive lanes take 8 consecutive rows of one 8-channel group (128 contiguous
   //      LDS bytes per ds_write_b128 lane group)
+  if (p.ln_w != nullptr) {
+    // LayerNorm prologue (nn.LayerNorm over the K values of a row, codec/transformer.py:113-114; Linear mode, 32 rows x 512 values =
+    // 4 items per thread): the tile is loaded once into registers; mean, then the variance about it (two passes, as the
+    // stand-alone kernel does), through per-(row, group) partial sums in LDS; (x - mean) * rstd * w + b goes into the pieces.
+    float4 va[4][2];
+    float* psum = reinterpret_cast<float*>(xp + 3 * G * XS_RA);  // [32 rows][64 groups], then mean[32], rstd[32]
+    float* stat = psum + 32 * 64;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + 512 * it, i = idx / (8 * G) * 8 + (idx & 7), g8 = (idx >> 3) % G;
+      va[it][0] = va[it][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + i < T) {
+        const float* src = xb + (long)i * p.ldx + g8 * 8;
+        va[it][0] = *reinterpret_cast<const float4*>(src);
+        va[it][1] = *reinterpret_cast<const float4*>(src + 4);
+      }
+      const float4 a = va[it][0], c = va[it][1];
+      psum[i * 64 + g8] = ((a.x + a.y) + (a.z + a.w)) + ((c.x + c.y) + (c.z + c.w));
+    }
+    lds_barrier();
+    const int srow = tid >> 4, l16 = tid & 15;  // 16 lanes per row
+    {
+      const float4 t = *reinterpret_cast<const float4*>(psum + srow * 64 + l16 * 4);
+      float sm = (t.x + t.y) + (t.z + t.w);
+      sm += __shfl_xor(sm, 8); sm += __shfl_xor(sm, 4); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 1);
+      if (l16 == 0) stat[srow] = sm / (float)p.K;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + 512 * it, i = idx / (8 * G) * 8 + (idx & 7), g8 = (idx >> 3) % G;
+      const float mu = stat[i];
+      const float4 a = va[it][0], c = va[it][1];
+      float v = 0.f;
+      v = fmaf(a.x - mu, a.x - mu, v); v = fmaf(a.y - mu, a.y - mu, v); v = fmaf(a.z - mu, a.z - mu, v); v = fmaf(a.w - mu, a.w - mu, v);
+      v = fmaf(c.x - mu, c.x - mu, v); v = fmaf(c.y - mu, c.y - mu, v); v = fmaf(c.z - mu, c.z - mu, v); v = fmaf(c.w - mu, c.w - mu, v);
+      psum[i * 64 + g8] = v;
+    }
+    lds_barrier();
+    {
+      const float4 t = *reinterpret_cast<const float4*>(psum + srow * 64 + l16 * 4);
+      float sm = (t.x + t.y) + (t.z + t.w);
+      sm += __shfl_xor(sm, 8); sm += __shfl_xor(sm, 4); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 1);
+      if (l16 == 0) stat[32 + srow] = 1.0f / sqrtf(sm / (float)p.K + p.eps);
+    }
+    lds_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + 512 * it, i = idx / (8 * G) * 8 + (idx & 7), g8 = (idx >> 3) % G;
+      const float mu = stat[i], rs = stat[32 + i];
+      const float4 w0 = *reinterpret_cast<const float4*>(p.ln_w + g8 * 8), w1 = *reinterpret_cast<const float4*>(p.ln_w + g8 * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(p.ln_b + g8 * 8), b1 = *reinterpret_cast<const float4*>(p.ln_b + g8 * 8 + 4);
+      float4 a = va[it][0], c = va[it][1];
+      a = make_float4((a.x - mu) * rs * w0.x + b0.x, (a.y - mu) * rs * w0.y + b0.y, (a.z - mu) * rs * w0.z + b0.z, (a.w - mu) * rs * w0.w + b0.w);
+      c = make_float4((c.x - mu) * rs * w1.x + b1.x, (c.y - mu) * rs * w1.y + b1.y, (c.z - mu) * rs * w1.z + b1.z, (c.w - mu) * rs * w1.w + b1.w);
+      uint4 h, m, l;
+      split3x8(a, c, h, m, l);
+      const int slot = g8 * XS_RA + i;
+      xp[slot] = h;
+      xp[slot + G * XS_RA] = m;
+      xp[slot + 2 * G * XS_RA] = l;
+    }
+  } else
   for (int idx = tid; idx < ((nrows + 7) & ~7) * G; idx += 512) {
     const int i = idx / (8 * G) * 8 + (idx & 7), g8 = (idx >> 3) % G;
     if (i >= nrows) continue;
@@ -124,7 +187,7 @@ __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
 
 template <int NTW, int MT, int RA, int EPI>
 int launch_xs(const GemmDev& g, int nsplit, hipStream_t stream) {
-  const size_t lds = (size_t)3 * (g.cpt * 4) * RA * 16;
+  const size_t lds = (size_t)3 * (g.cpt * 4) * RA * 16 + (g.ln_w ? (32 * 64 + 64) * sizeof(float) : 0);
   static size_t attr = 0;
   if (lds > attr) {  // > 64 KB of dynamic LDS must be requested per kernel
     ST_CHECK_HIP(hipFuncSetAttribute((const void*)conv_xs_kernel<NTW, MT, RA, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -164,11 +227,12 @@ bool conv_xs_applies(const GemmDev& d, int epilogue) {
   if (d.x_bstride % 4 != 0 || d.ldo % 4 != 0 || d.o_bstride % 4 != 0 || d.ldx % 4 != 0) return false;
   if (d.ldx >= d.K) {  // Linear
     if (lin_off || d.pro_elu || d.K > XS_MAX_K_LINEAR || d.K % 32 != 0 || linear_ntw(d, epilogue) == 0) return false;
+    if (d.ln_w && (d.rows_per_batch > 0 || d.K != 512 || !d.ln_b)) return false;  // the LayerNorm prologue: 32-row tiles of 512 values
     if (d.rows_per_batch > 0)
       return d.M % d.rows_per_batch == 0 && d.M / d.rows_per_batch <= 65535 && (long)((d.rows_per_batch + 63) / 64) * (d.M / d.rows_per_batch) >= 256;
     return (long)((d.M + 31) / 32) * 4 >= 256;
   }
-  if (epilogue != SMOLTTS_EPI_STORE || d.rows_per_batch <= 0 || d.M % d.rows_per_batch != 0) return false;
+  if (d.ln_w || epilogue != SMOLTTS_EPI_STORE || d.rows_per_batch <= 0 || d.M % d.rows_per_batch != 0) return false;
   if (d.ldx % 32 != 0 || d.ldx > XS_MAX_CIN || d.K % d.ldx != 0) return false;
   const int taps = (int)(d.K / d.ldx);
   if (taps < 2 || 64 + taps - 1 > XS_RA_CONV || (d.N != 128 && d.N != 640)) return false;

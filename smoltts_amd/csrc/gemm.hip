@@ -61,10 +61,51 @@ __global__ __launch_bounds__(MT >= 4 ? 512 : 1024) void gemm_kernel(GemmDev p) {
   const char* wt = p.w + (size_t)nt * nchunks * WBYTES + lane * 16;
   STAMP(0);
 
+  // LayerNorm prologue: mean and rstd of the workgroup's rows first (two passes over each row, a wave per row; the second pass
+  // re-reads the row from L1 / L2), kept in LDS behind the reduction buffers; x is normalised as it is loaded below.
+  float ln_mu[MT], ln_rs[MT];
+  if (PRO == SMOLTTS_PRO_LAYERNORM) {
+    float* stat = smem + nwaves * MT * (256 + 16);  // [MT * 16][2]
+    // (the dispatcher sends only calls of at most 16 rows and K <= 512 here: a wave has at most 4 rows, whose values it keeps in
+    // registers between the two passes -- all its loads are in flight together)
+    constexpr int RPW = 4;
+    float4 xv4[RPW][2];
+    bool on[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int rr = wave + i * nwaves, m = mg * MT * 16 + rr;
+      on[i] = rr < MT * 16 && m < p.M;
+      xv4[i][0] = xv4[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (on[i]) {
+        const float* xr = p.x + row_off(m, p.rows_per_batch, p.ldx, p.x_bstride);
+        if (lane * 4 < p.K) xv4[i][0] = *reinterpret_cast<const float4*>(xr + lane * 4);
+        if (256 + lane * 4 < p.K) xv4[i][1] = *reinterpret_cast<const float4*>(xr + 256 + lane * 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int rr = wave + i * nwaves;
+      const float4 a = xv4[i][0], c = xv4[i][1];
+      float sm = ((a.x + a.y) + (a.z + a.w)) + ((c.x + c.y) + (c.z + c.w));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+      const float mu = sm / (float)p.K;
+      float v = 0.f;
+      if (lane * 4 < p.K) { v = fmaf(a.x - mu, a.x - mu, v); v = fmaf(a.y - mu, a.y - mu, v); v = fmaf(a.z - mu, a.z - mu, v); v = fmaf(a.w - mu, a.w - mu, v); }
+      if (256 + lane * 4 < p.K) { v = fmaf(c.x - mu, c.x - mu, v); v = fmaf(c.y - mu, c.y - mu, v); v = fmaf(c.z - mu, c.z - mu, v); v = fmaf(c.w - mu, c.w - mu, v); }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0 && rr < MT * 16) { stat[rr * 2] = on[i] ? mu : 0.f; stat[rr * 2 + 1] = on[i] ? 1.0f / sqrtf(v / (float)p.K + p.eps) : 0.f; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { ln_mu[mt] = stat[(mt * 16 + r) * 2]; ln_rs[mt] = stat[(mt * 16 + r) * 2 + 1]; }
+  }
+
   for (int c0 = wave; c0 < nchunks; c0 += nwaves * U) {
     uint4 wraw[U][WF32 ? 2 : 1];
     float4 xa[U][MT][2];
-    float4 ga[U][2];
+    float4 ga[U][2], gb[U][2];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int c = c0 + u * nwaves;
@@ -73,9 +114,13 @@ __global__ __launch_bounds__(MT >= 4 ? 512 : 1024) void gemm_kernel(GemmDev p) {
         wraw[u][0] = *reinterpret_cast<const uint4*>(wp);
         if (WF32) wraw[u][WF32 ? 1 : 0] = *reinterpret_cast<const uint4*>(wp + 1024);
         const int k0 = c * 32 + q * 8;
-        if (PRO == SMOLTTS_PRO_RMSNORM) {
+        if (PRO == SMOLTTS_PRO_RMSNORM || PRO == SMOLTTS_PRO_LAYERNORM) {
           ga[u][0] = *reinterpret_cast<const float4*>(p.gamma + k0);
           ga[u][1] = *reinterpret_cast<const float4*>(p.gamma + k0 + 4);
+        }
+        if (PRO == SMOLTTS_PRO_LAYERNORM) {
+          gb[u][0] = *reinterpret_cast<const float4*>(p.ln_b + k0);
+          gb[u][1] = *reinterpret_cast<const float4*>(p.ln_b + k0 + 4);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -91,6 +136,7 @@ __global__ __launch_bounds__(MT >= 4 ? 512 : 1024) void gemm_kernel(GemmDev p) {
         wraw[u][0] = make_uint4(0, 0, 0, 0);
         if (WF32) wraw[u][WF32 ? 1 : 0] = make_uint4(0, 0, 0, 0);
         ga[u][0] = ga[u][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gb[u][0] = gb[u][1] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           xa[u][mt][0] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -112,10 +158,14 @@ __global__ __launch_bounds__(MT >= 4 ? 512 : 1024) void gemm_kernel(GemmDev p) {
         wv[4] = bf16_lo(wraw[u][0].z); wv[5] = bf16_hi(wraw[u][0].z);
         wv[6] = bf16_lo(wraw[u][0].w); wv[7] = bf16_hi(wraw[u][0].w);
       }
-      float gv[8];
-      if (PRO == SMOLTTS_PRO_RMSNORM) {
+      float gv[8], bv[8];
+      if (PRO == SMOLTTS_PRO_RMSNORM || PRO == SMOLTTS_PRO_LAYERNORM) {
         gv[0] = ga[u][0].x; gv[1] = ga[u][0].y; gv[2] = ga[u][0].z; gv[3] = ga[u][0].w;
         gv[4] = ga[u][1].x; gv[5] = ga[u][1].y; gv[6] = ga[u][1].z; gv[7] = ga[u][1].w;
+      }
+      if (PRO == SMOLTTS_PRO_LAYERNORM) {
+        bv[0] = gb[u][0].x; bv[1] = gb[u][0].y; bv[2] = gb[u][0].z; bv[3] = gb[u][0].w;
+        bv[4] = gb[u][1].x; bv[5] = gb[u][1].y; bv[6] = gb[u][1].z; bv[7] = gb[u][1].w;
       }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -129,6 +179,8 @@ __global__ __launch_bounds__(MT >= 4 ? 512 : 1024) void gemm_kernel(GemmDev p) {
             xj *= gv[j];
           } else if (PRO == SMOLTTS_PRO_ELU) {
             xj = elu1(xj);
+          } else if (PRO == SMOLTTS_PRO_LAYERNORM) {
+            xj = (xj - ln_mu[mt]) * ln_rs[mt] * gv[j] + bv[j];  // (a chunk beyond K carries zero weights: its value is irrelevant)
           }
           acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], xj, acc[mt], 0, 0, 0);
         }
@@ -379,7 +431,7 @@ static int launch_rows(const GemmDev& d, hipStream_t stream) {
 template <bool WF32, int MT, int U, int PRO, int EPI>
 static int launch_one(const GemmDev& d, int nwaves, hipStream_t stream) {
   const dim3 grid((d.N + 15) / 16, (d.M + 16 * MT - 1) / (16 * MT));
-  const size_t lds = (size_t)nwaves * MT * (256 + 16) * sizeof(float);
+  const size_t lds = ((size_t)nwaves * MT * (256 + 16) + (PRO == SMOLTTS_PRO_LAYERNORM ? MT * 32 : 0)) * sizeof(float);
   hipLaunchKernelGGL((gemm_kernel<WF32, MT, U, PRO, EPI>), grid, dim3(nwaves * 64), lds, stream, d);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
@@ -451,6 +503,7 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
   d.rows_per_batch = a.rows_per_batch; d.M = a.M; d.N = a.N; d.K = a.K; d.gamma = a.gamma_dev; d.eps = a.eps;
   d.bias = a.bias_dev; d.scale = a.scale_dev; d.resid = a.resid_dev; d.out = a.out_dev; d.ldo = a.ldo;
   d.raw_out = a.raw_out_dev; d.raw_bstride = a.raw_bstride; d.elu_out = a.elu_out; d.pro_elu = a.prologue == SMOLTTS_PRO_ELU;
+  d.ln_w = nullptr; d.ln_b = nullptr;
   d.o_bstride = a.o_bstride; d.ldr = a.ldr ? a.ldr : a.ldo; d.r_bstride = a.ldr ? a.r_bstride : a.o_bstride;
   d.rope = a.rope_dev; d.row_pos = a.row_pos_dev; d.row_slot = a.row_slot_dev;
   d.kc = a.k_cache_dev; d.vc = a.v_cache_dev; d.n_q_heads = a.n_q_heads; d.n_kv_heads = a.n_kv_heads;
@@ -487,6 +540,24 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
     const int WN = per >= 4 ? 4 : (per >= 2 ? 2 : 1);
     rows_grid = (long)((per + WN - 1) / WN) * ((a.M + 64 * (4 / WN) - 1) / (64 * (4 / WN)));
   }
+  if (P == SMOLTTS_PRO_LAYERNORM) {
+    ST_REQUIRE(a.w_is_fp32 && a.gamma_dev && a.beta_dev && a.rows_per_batch == 0 && a.K % 4 == 0, SMOLTTS_E_INVALID,
+               "gemm: the LayerNorm prologue needs fp32 weights, weight and bias, and one flat row range");
+    d.ln_w = a.gamma_dev; d.ln_b = a.beta_dev;
+    const bool many_b3 = a.w3_dev && gemm_b3_applies(a.M, a.N, a.K, E);
+    if (many_b3 && conv_xs_applies(d, E)) return launch_conv_xs(d, E, stream);  // fused (row-stationary kernel, K = 512)
+    const bool many_rows = a.M >= 1024 && rows_grid >= 192;
+    // (in the skinny kernel every workgroup works out the statistics of all its rows itself: worth it for a handful of rows only --
+    // measured: 32 slots x 1 frame = 64 rows 0.74 -> 0.95 ms with it, 1 slot x 1 frame 0.39 -> 0.36 ms)
+    if (many_b3 || many_rows || a.M > 16 || a.K > 512 || !(E == SMOLTTS_EPI_QKV_ROPE || E == SMOLTTS_EPI_GELU)) {
+      // no such prologue in the kernel this shape goes to: the stand-alone LayerNorm first
+      ST_REQUIRE(a.ln_scratch_dev && a.ldx == a.K, SMOLTTS_E_INVALID, "gemm: LayerNorm prologue: scratch missing or strided rows");
+      ST_TRY(launch_layernorm(a.x_dev, a.gamma_dev, a.beta_dev, a.M, a.K, a.eps, a.ln_scratch_dev, stream));
+      SmolttsGemmArgs b = a;
+      b.prologue = SMOLTTS_PRO_NONE; b.x_dev = a.ln_scratch_dev; b.gamma_dev = nullptr;
+      return launch_gemm_impl(b, stream);
+    }
+  }
   if (a.w_is_fp32 && a.w3_dev && (P == SMOLTTS_PRO_NONE || P == SMOLTTS_PRO_ELU) && gemm_b3_applies(a.M, a.N, a.K, E) && !(E == SMOLTTS_EPI_STORE && a.N < 4))
     return launch_gemm_b3(d, E, stream);
   if (a.w_is_fp32 && P == SMOLTTS_PRO_NONE && a.M >= 1024 && rows_grid >= 192) {
@@ -516,6 +587,8 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
   ST_CASE(true, SMOLTTS_PRO_NONE, SMOLTTS_EPI_RESID)
   ST_CASE(true, SMOLTTS_PRO_ELU, SMOLTTS_EPI_STORE)
   ST_CASE(true, SMOLTTS_PRO_ELU, SMOLTTS_EPI_RESID)
+  ST_CASE(true, SMOLTTS_PRO_LAYERNORM, SMOLTTS_EPI_QKV_ROPE)
+  ST_CASE(true, SMOLTTS_PRO_LAYERNORM, SMOLTTS_EPI_GELU)
 #undef ST_CASE
   set_error("gemm: unsupported combination w_is_fp32=%d prologue=%d epilogue=%d", a.w_is_fp32, P, E);
   return SMOLTTS_E_INVALID;

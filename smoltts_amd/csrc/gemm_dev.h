@@ -22,6 +22,8 @@ struct GemmDev {
   long raw_bstride;
   int elu_out;     // apply ELU to what goes to `out`
   int pro_elu;     // gemm_b3: apply ELU to X as it is staged (the producer stored the raw tensor only)
+  const float* ln_w;  // LayerNorm prologue (conv_xs Linear mode, the skinny kernel): weight / bias [K]; eps in `eps`; nullptr = none
+  const float* ln_b;
   long ldr, r_bstride;
   const float* rope;
   const int* row_pos;

@@ -190,9 +190,10 @@ int run_mimi_transformer(const char* A, const SmolttsMimiLayerWeights* layers, i
     const SmolttsMimiLayerWeights& lw = layers[l];
     float* kc = b.kc + l * b.layer_stride;
     float* vc = b.vc + l * b.layer_stride;
-    ST_TRY(launch_layernorm(b.tx, (const float*)(A + lw.ln1_w), (const float*)(A + lw.ln1_b), R, D, 1e-5f, b.tn, st));
-    {
-      SmolttsGemmArgs a = mimi_gemm_f32(A + lw.wqkv, b.tn, D, R, 3 * D, D, lw.wqkv3 ? A + lw.wqkv3 : nullptr);
+    {  // LayerNorm (as the GEMM's prologue where its kernel has one, else through b.tn) + QKV + RoPE + cache write
+      SmolttsGemmArgs a = mimi_gemm_f32(A + lw.wqkv, b.tx, D, R, 3 * D, D, lw.wqkv3 ? A + lw.wqkv3 : nullptr);
+      a.prologue = SMOLTTS_PRO_LAYERNORM; a.gamma_dev = (const float*)(A + lw.ln1_w); a.beta_dev = (const float*)(A + lw.ln1_b);
+      a.eps = 1e-5f; a.ln_scratch_dev = b.tn;
       a.epilogue = SMOLTTS_EPI_QKV_ROPE; a.out_dev = b.tq; a.ldo = D;
       a.rope_dev = rope; a.row_pos_dev = b.row_pos; a.row_slot_dev = b.row_slot;
       a.k_cache_dev = kc; a.v_cache_dev = vc;
@@ -206,9 +207,10 @@ int run_mimi_transformer(const char* A, const SmolttsMimiLayerWeights* layers, i
       a.resid_dev = b.tx; a.out_dev = b.tx; a.ldo = D;
       ST_TRY(launch_gemm(a, st));
     }
-    ST_TRY(launch_layernorm(b.tx, (const float*)(A + lw.ln2_w), (const float*)(A + lw.ln2_b), R, D, 1e-5f, b.tn, st));
     {
-      SmolttsGemmArgs a = mimi_gemm_f32(A + lw.fc1, b.tn, D, R, FF, D, lw.fc13 ? A + lw.fc13 : nullptr);
+      SmolttsGemmArgs a = mimi_gemm_f32(A + lw.fc1, b.tx, D, R, FF, D, lw.fc13 ? A + lw.fc13 : nullptr);
+      a.prologue = SMOLTTS_PRO_LAYERNORM; a.gamma_dev = (const float*)(A + lw.ln2_w); a.beta_dev = (const float*)(A + lw.ln2_b);
+      a.eps = 1e-5f; a.ln_scratch_dev = b.tn;
       a.epilogue = SMOLTTS_EPI_GELU; a.out_dev = b.th; a.ldo = FF;
       ST_TRY(launch_gemm(a, st));
     }

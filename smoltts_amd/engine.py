@@ -58,6 +58,7 @@ class GemmArgs(C.Structure):
         ("row_pos_dev", C.c_void_p), ("row_slot_dev", C.c_void_p), ("k_cache_dev", C.c_void_p),
         ("v_cache_dev", C.c_void_p), ("n_q_heads", C.c_int32), ("n_kv_heads", C.c_int32), ("cache_len", C.c_int32),
         ("w3_dev", C.c_void_p), ("splitk_ws_dev", C.c_void_p), ("splitk_ws_floats", C.c_int64),
+        ("beta_dev", C.c_void_p), ("ln_scratch_dev", C.c_void_p),
     ]
 
 
@@ -90,7 +91,7 @@ class MimiEncWeights(C.Structure):
                 ("in_proj", C.c_uint64 * 2), ("codebooks_t", C.c_uint64), ("codebooks", C.c_uint64), ("codebook_sq", C.c_uint64)]
 
 
-PRO_NONE, PRO_RMSNORM, PRO_ELU = 0, 1, 2
+PRO_NONE, PRO_RMSNORM, PRO_ELU, PRO_LAYERNORM = 0, 1, 2, 3
 KV_FORMATS = {"fp32": 0, "bf16": 1}  # SMOLTTS_KV_*
 EPI_STORE, EPI_RESID, EPI_SWIGLU, EPI_GELU, EPI_SCALE_RESID, EPI_QKV_ROPE = range(6)
 

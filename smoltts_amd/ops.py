@@ -38,7 +38,8 @@ def linear(x: torch.Tensor, w_tiles: torch.Tensor, N: int, *, w_fp32: bool = Fal
            row_slot: Optional[torch.Tensor] = None, k_cache: Optional[torch.Tensor] = None,
            v_cache: Optional[torch.Tensor] = None, n_q_heads: int = 0, n_kv_heads: int = 0, cache_len: int = 0,
            elu_out: bool = False, raw_out: Optional[torch.Tensor] = None, raw_bstride: int = 0,
-           w3: Optional[torch.Tensor] = None, splitk_ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+           w3: Optional[torch.Tensor] = None, splitk_ws: Optional[torch.Tensor] = None,
+           beta: Optional[torch.Tensor] = None, ln_scratch: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``w3`` (``pack_weight_w3`` of the same fp32 matrix): many-row calls run the bf16x3-split kernel (gemm_b3.hip)."""
     lib = E.load_library()
     M = x.shape[0] if M is None else M
@@ -62,6 +63,7 @@ def linear(x: torch.Tensor, w_tiles: torch.Tensor, N: int, *, w_fp32: bool = Fal
     a.n_q_heads, a.n_kv_heads, a.cache_len = n_q_heads, n_kv_heads, cache_len
     a.w3_dev = E.dptr(w3)
     a.splitk_ws_dev, a.splitk_ws_floats = E.dptr(splitk_ws), (splitk_ws.numel() if splitk_ws is not None else 0)
+    a.beta_dev, a.ln_scratch_dev = E.dptr(beta), E.dptr(ln_scratch)
     E.check(lib.smoltts_k_gemm(C.byref(a), E.current_stream_ptr()), "smoltts_k_gemm")
     return out
 

@@ -156,6 +156,47 @@ def test_k1_conv_plus_residual_over_slots(E, ops, K, N, T, B):
     assert rel_err(got, ref) < 2e-6 and rel_err(got, ref) < 4 * rel_err(old, ref) + 2e-7
 
 
+@pytest.mark.parametrize("M", [2, 7, 33, 70, 600, 2048, 2077])
+def test_layernorm_prologue(E, ops, M):
+    """nn.LayerNorm as the GEMM's prologue: fused into the skinny kernel (few rows), into the row-stationary kernel (>= 2048 rows,
+    K = 512) or applied by the stand-alone kernel into the scratch first (the shapes in between) -- fc1 (GELU) and wqkv (RoPE +
+    cache scatter) of the decoder transformer, against float64 / against the unfused pair of launches."""
+    g = torch.Generator().manual_seed(77 + M)
+    K, N = 512, 2048
+    x = torch.randn(M, K, generator=g) * torch.logspace(-1, 1, K)[None] + 0.3
+    lw, lb = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    w, b = torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    w32, w3 = ops.pack_weight(w, fp32=True), ops.pack_weight_w3(w)
+    ref = F.gelu(F.layer_norm(x.double(), (K,), lw.double(), lb.double(), 1e-5) @ w.double().T + b.double())
+    scratch = torch.zeros(M, K, device="cuda")
+    got = ops.linear(x.cuda(), w32, N, w_fp32=True, prologue=E.PRO_LAYERNORM, gamma=lw.cuda(), beta=lb.cuda(), eps=1e-5, ln_scratch=scratch,
+                     epilogue=E.EPI_GELU, bias=b.cuda(), w3=w3).cpu()
+    two = ops.linear(ops.layernorm(x.cuda(), lw.cuda(), lb.cuda()), w32, N, w_fp32=True, epilogue=E.EPI_GELU, bias=b.cuda(), w3=w3).cpu()
+    print(f"M={M}: fused {rel_err(got, ref):.2e}, two launches {rel_err(two, ref):.2e}")
+    assert rel_err(got, ref) < 3e-6 and rel_err(got, ref) < 4 * rel_err(two, ref) + 3e-7
+    # wqkv: q rows and the K / V scatter equal the unfused pair's within fp32 rounding
+    H, cache_len, slots = 8, 64, (M + 63) // 64
+    Nq = 3 * H * 64
+    wq = torch.randn(Nq, K, generator=g) / math.sqrt(K)
+    wq32, wq3 = ops.pack_weight(wq, fp32=True), ops.pack_weight_w3(wq)
+    pairs = torch.randperm(slots * cache_len, generator=g)[:M]
+    row_slot, row_pos = (pairs // cache_len).int().cuda(), (pairs % cache_len).int().cuda()
+    ang = torch.outer(torch.arange(cache_len).float(), 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64)))
+    rope = torch.stack([ang.cos(), ang.sin()], -1).contiguous().cuda()
+    outs = []
+    for fused in (True, False):
+        kc, vc = torch.zeros(slots, H, cache_len, 64).cuda(), torch.zeros(slots, H, cache_len, 64).cuda()
+        kw = dict(w_fp32=True, epilogue=E.EPI_QKV_ROPE, rope=rope, row_pos=row_pos, row_slot=row_slot, k_cache=kc, v_cache=vc,
+                  n_q_heads=H, n_kv_heads=H, cache_len=cache_len, w3=wq3)
+        if fused:
+            q = ops.linear(x.cuda(), wq32, Nq, prologue=E.PRO_LAYERNORM, gamma=lw.cuda(), beta=lb.cuda(), eps=1e-5, ln_scratch=scratch, **kw)
+        else:
+            q = ops.linear(ops.layernorm(x.cuda(), lw.cuda(), lb.cuda()), wq32, Nq, **kw)
+        outs.append((q.cpu(), kc.cpu(), vc.cpu()))
+    for a_, b_ in zip(*outs):
+        assert rel_err(a_, b_) < 3e-6
+
+
 def test_b3_epilogues(E, ops):
     g = torch.Generator().manual_seed(5)
     M, K, N = 1024, 512, 512
