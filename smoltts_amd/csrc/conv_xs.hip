@@ -39,8 +39,11 @@ __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
   const int r = lane & 15, q = lane >> 4;
   const int b = blockIdx.y, row0 = blockIdx.x * XS_S, T = p.rows_per_batch > 0 ? p.rows_per_batch : p.M;
   const int G = p.cpt * 4, nrows = XS_S + p.taps - 1, nchunks = p.K >> 5;  // G 8-value groups per window row
-  const int nt0 = (int)blockIdx.z * 8 * NTW + wave * NTW;                   // the wave's first column tile
-  const float* xb = p.x + (long)b * p.x_bstride + (long)row0 * p.ldx;
+  // blockIdx.z: the part of the column tiles (N split over workgroups), or -- ksplit > 1 -- the part of K (partial sums out)
+  const int kz = p.ksplit > 1 ? (int)blockIdx.z : 0;
+  const int nt0 = (p.ksplit > 1 ? 0 : (int)blockIdx.z * 8 * NTW) + wave * NTW;  // the wave's first column tile
+  const int nloc = p.ksplit > 1 ? p.cpt : nchunks;                               // chunks this workgroup runs over
+  const float* xb = p.x + (long)b * p.x_bstride + (long)row0 * p.ldx + (long)kz * p.cpt * 32;
 
   // ---- the tile's window rows -> pieces; 8 consecutive lanes take 8 consecutive rows of one 8-channel group (128 contiguous
   //      LDS bytes per ds_write_b128 lane group)
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
     for (int t = 0; t < NTW; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // W3 tile (column tile nt, chunk kc) at (nt * nchunks + kc) * 3072: the wave's tiles are NTW * nchunks consecutive tiles
-  const char* wtile = p.w3 + (size_t)nt0 * nchunks * 3072;
+  const char* wtile = p.w3 + ((size_t)nt0 * nchunks + (size_t)kz * p.cpt) * 3072;
   const int wlane = lane * 16;
   uint4 wq[2][NTW][3];
 #pragma unroll
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
   int tap = 0, xc = 0;  // chunk kc = tap * cpt + xc: k = tap * C_in + 32 xc ..
 #define XS_CHUNK(BUF, KC)                                                                                               \
   {                                                                                                                     \
-    if ((KC) + 1 < nchunks) {                                                                                           \
+    if ((KC) + 1 < nloc) {                                                                                              \
       _Pragma("unroll") for (int t = 0; t < NTW; ++t)                                                                   \
         _Pragma("unroll") for (int pc = 0; pc < 3; ++pc)                                                                \
           wq[(BUF) ^ 1][t][pc] = *reinterpret_cast<const uint4*>(wtile + (size_t)(t * nchunks + (KC) + 1) * 3072 + pc * 1024 + wlane); \
@@ -163,11 +166,11 @@ __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
     if (++xc == p.cpt) { xc = 0; ++tap; }                                                                               \
   }
   int kc = 0;
-  for (; kc + 1 < nchunks; kc += 2) {
+  for (; kc + 1 < nloc; kc += 2) {
     XS_CHUNK(0, kc)
     XS_CHUNK(1, kc + 1)
   }
-  if (kc < nchunks) XS_CHUNK(0, kc)
+  if (kc < nloc) XS_CHUNK(0, kc)
 #undef XS_CHUNK
 
   // ---- epilogue from the accumulators: the lane holds out[row mt * 16 + r][n0 .. n0 + 4)
@@ -179,8 +182,13 @@ __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
     const long orow = row_off(m, p.rows_per_batch, p.ldo, p.o_bstride);
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
+      const int n0 = (nt0 + t) * 16 + q * 4;
+      if (p.ksplit > 1) {  // partial sums [part][M][N]; splitk_reduce_kernel adds them in fixed order and applies the epilogue
+        *reinterpret_cast<float4*>(p.splitk_ws + ((long)kz * p.M + m) * p.N + n0) = make_float4(acc[mt][t][0], acc[mt][t][1], acc[mt][t][2], acc[mt][t][3]);
+        continue;
+      }
       float v[4] = {acc[mt][t][0], acc[mt][t][1], acc[mt][t][2], acc[mt][t][3]};
-      rows_epilogue<EPI>(p, m, orow, (nt0 + t) * 16 + q * 4, v);
+      rows_epilogue<EPI>(p, m, orow, n0, v);
     }
   }
 }
@@ -198,6 +206,12 @@ int launch_xs(const GemmDev& g, int nsplit, hipStream_t stream) {
   hipLaunchKernelGGL((conv_xs_kernel<NTW, MT, RA, EPI>), grid, dim3(512), lds, stream, g);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
+}
+
+// fc2 of the decoder transformer (K = 2048, N = 512, layer scale + residual): K in four parts of 512, one workgroup each
+// (32 rows x all 32 column tiles), partial sums to the split-K workspace, then the fixed-order reduce + epilogue pass.
+bool linear_ksplit(const GemmDev& d, int epilogue) {
+  return epilogue == SMOLTTS_EPI_SCALE_RESID && d.N == 512 && d.K == 2048 && d.splitk_ws && 4L * d.M * d.N <= d.splitk_cap;
 }
 
 // Linear shapes: (N, epilogue) -> column tiles per wave.  The transformer's Linears (one flat row range): 32-row tiles, the
@@ -225,6 +239,11 @@ bool conv_xs_applies(const GemmDev& d, int epilogue) {
   static const bool lin_off = [] { const char* e = getenv("SMOLTTS_LINEAR_XS"); return e && atoi(e) == 0; }();
   if (off || !d.w3) return false;
   if (d.x_bstride % 4 != 0 || d.ldo % 4 != 0 || d.o_bstride % 4 != 0 || d.ldx % 4 != 0) return false;
+  if (d.ldx >= d.K && linear_ksplit(d, epilogue)) {
+    if (lin_off || d.pro_elu || d.ln_w) return false;
+    const int T = d.rows_per_batch > 0 ? d.rows_per_batch : d.M;
+    return d.M % T == 0 && d.M / T <= 65535 && (long)((T + 31) / 32) * (d.M / T) * 4 >= 256;
+  }
   if (d.ldx >= d.K) {  // Linear
     if (lin_off || d.pro_elu || d.K > XS_MAX_K_LINEAR || d.K % 32 != 0 || linear_ntw(d, epilogue) == 0) return false;
     if (d.ln_w && (d.rows_per_batch > 0 || d.K != 512 || !d.ln_b)) return false;  // the LayerNorm prologue: 32-row tiles of 512 values
@@ -242,6 +261,15 @@ bool conv_xs_applies(const GemmDev& d, int epilogue) {
 
 int launch_conv_xs(const GemmDev& d, int epilogue, hipStream_t stream) {
   GemmDev g = d;
+  if (d.ldx >= d.K && linear_ksplit(d, epilogue)) {
+    g.taps = 1;
+    g.cpt = 16;  // chunks per K part
+    g.ksplit = 4;
+    ST_TRY((launch_xs<4, 2, 32, SMOLTTS_EPI_SCALE_RESID>(g, 4, stream)));
+    hipLaunchKernelGGL((splitk_reduce_kernel<SMOLTTS_EPI_SCALE_RESID>), dim3((unsigned)(((long)d.M * (d.N >> 2) + 255) / 256)), dim3(256), 0, stream, g);
+    ST_CHECK_HIP(hipGetLastError());
+    return SMOLTTS_OK;
+  }
   if (d.ldx >= d.K) {  // Linear: one "tap" of K values
     g.taps = 1;
     g.cpt = d.K >> 5;

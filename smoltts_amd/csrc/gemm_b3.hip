@@ -154,21 +154,6 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmDev p) {
   }
 }
 
-// out[m][n0..n0+4) = epilogue( sum over the splits, in split order )
-template <int EPI>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmDev p) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // one float4 of the [M][N] result
-  const int n4 = p.N >> 2;
-  if (i >= (long)p.M * n4) return;
-  const int m = (int)(i / n4), n0 = (int)(i - (long)m * n4) * 4;
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < p.ksplit; ++s) {
-    const float4 t = *reinterpret_cast<const float4*>(p.splitk_ws + ((long)s * p.M + m) * p.N + n0);
-    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-  }
-  rows_epilogue<EPI>(p, m, row_off(m, p.rows_per_batch, p.ldo, p.o_bstride), n0, v);
-}
-
 // Tile choice, measured on the 16 GEMM shapes of a 1024-frame chunk (tools/microbench_b3.py with SMOLTTS_B3_TILE forced):
 // 128 x 128 tiles win once they make >= 2 workgroups per CU (ConvTranspose stages); below that the 64 x 64 tiles win although
 // they re-read more -- at M = 2048 (conv0, the transformer Linears) what counts is workgroups in flight per CU (5 fit), e.g.

@@ -133,6 +133,21 @@ __device__ __forceinline__ f32x4 mfma_b3(const uint4 w[3], const uint4 x[3], f32
   return acc;
 }
 
+// out[m][n0..n0+4) = epilogue( sum over the splits, in split order )
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmDev p) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // one float4 of the [M][N] result
+  const int n4 = p.N >> 2;
+  if (i >= (long)p.M * n4) return;
+  const int m = (int)(i / n4), n0 = (int)(i - (long)m * n4) * 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < p.ksplit; ++s) {
+    const float4 t = *reinterpret_cast<const float4*>(p.splitk_ws + ((long)s * p.M + m) * p.N + n0);
+    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+  }
+  rows_epilogue<EPI>(p, m, row_off(m, p.rows_per_batch, p.ldo, p.o_bstride), n0, v);
+}
+
 int launch_gemm_b3(const GemmDev& d, int epilogue, hipStream_t stream);  // gemm_b3.hip
 bool gemm_b3_applies(int M, int N, int K, int epilogue);
 int launch_conv_xs(const GemmDev& d, int epilogue, hipStream_t stream);  // conv_xs.hip: conv windows of <= 256 channels / Linears of K <= 512, X stationary in LDS
