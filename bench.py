@@ -101,8 +101,12 @@ def parse_args(argv=None):
 def self_launch(n: int, argv) -> int:
     """Parent of an N-rank run: spawn one child per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
     torch.distributed.run sets them), relay rank 0's stdout, return the first non-zero exit code (0 if none).  This
-    process makes no GPU call (it does not even import torch); a failing rank takes the others down with it (killed by
-    PID) instead of leaving them stuck in a collective."""
+    process makes no GPU call (it does not even import torch).  Every child runs in a session of its own and sees exactly
+    one GPU (HIP_VISIBLE_DEVICES = its entry of the parent's device list, set before the child's first GPU call;
+    SMOLTTS_BENCH_PIN_DEVICES=0 leaves the binding to LOCAL_RANK -> torch.cuda.set_device as under torch.distributed.run).
+    A failing rank takes the others down with it, and so does a signal to the parent (SIGTERM / SIGINT from a driver's
+    timeout or Ctrl-C): children are terminated, then killed, by PID -- none is left holding a GPU."""
+    import signal
     import socket
     import subprocess
     import threading
@@ -110,42 +114,71 @@ def self_launch(n: int, argv) -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    pin = os.environ.get("SMOLTTS_BENCH_PIN_DEVICES", "1") != "0" and os.environ.get("SMOLTTS_BENCH_ONE_DEVICE") != "1"
+    visible = [d for d in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if d.strip()] or [str(i) for i in range(n)]
+    if pin and len(visible) < n:
+        print(f"[bench launcher] HIP_VISIBLE_DEVICES lists {len(visible)} devices for {n} ranks", file=sys.stderr, flush=True)
+        return 2
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
-        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None, text=(r == 0) or None))
 
-    def relay(p):  # the result line goes to stdout; anything else a library prints there (gloo / RCCL banners) to stderr
-        for line in p.stdout:
-            dst = sys.stdout if line.lstrip().startswith("{") else sys.stderr
-            dst.write(line)
-            dst.flush()
+    def stop_children(grace=15.0):
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            p.terminate()
+        t_end = time.time() + grace
+        for p in live:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
 
-    t = threading.Thread(target=relay, args=(procs[0],), daemon=True)
-    t.start()
+    got_signal = []
+
+    def on_signal(signum, _frame):
+        got_signal.append(signum)
+
+    old_handlers = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
     rc = 0
-    live = set(range(n))
-    while live and rc == 0:
-        time.sleep(0.05)
-        for r in list(live):
-            code = procs[r].poll()
-            if code is not None:
-                live.discard(r)
-                if code != 0:
-                    rc = code
-                    print(f"[bench launcher] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr, flush=True)
-    for r in live:  # only after a failure
-        procs[r].terminate()
-    for r in live:
-        try:
-            procs[r].wait(timeout=15)
-        except subprocess.TimeoutExpired:
-            procs[r].kill()
-            procs[r].wait()
-    t.join(timeout=5)
+    t = None
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+            if pin:
+                env["HIP_VISIBLE_DEVICES"] = visible[r]
+                env["SMOLTTS_BENCH_PINNED"] = "1"  # the rank's one visible GPU is device 0
+            procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env, start_new_session=True,
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None, text=(r == 0) or None))
+
+        def relay(p):  # the result line goes to stdout; anything else a library prints there (gloo / RCCL banners) to stderr
+            for line in p.stdout:
+                dst = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+                dst.write(line)
+                dst.flush()
+
+        t = threading.Thread(target=relay, args=(procs[0],), daemon=True)
+        t.start()
+        live = set(range(n))
+        while live and rc == 0 and not got_signal:
+            time.sleep(0.05)
+            for r in list(live):
+                code = procs[r].poll()
+                if code is not None:
+                    live.discard(r)
+                    if code != 0:
+                        rc = code
+                        print(f"[bench launcher] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr, flush=True)
+        if got_signal:
+            rc = 128 + got_signal[0]
+            print(f"[bench launcher] signal {got_signal[0]}: stopping the ranks", file=sys.stderr, flush=True)
+    finally:
+        stop_children()  # (a no-op when every rank has exited by itself)
+        for sig, h in old_handlers.items():
+            signal.signal(sig, h)
+        if t is not None:
+            t.join(timeout=5)
     return rc
 
 
@@ -178,11 +211,18 @@ def rehearse(args) -> None:
     parallel.barrier()
     elapsed = parallel.all_reduce_max(time.perf_counter() - t0, "cpu")
     units = parallel.all_reduce_sum(float(len(mine)), "cpu")
-    sums = parallel.all_gather_floats(float(arena.to(torch.int64).sum()), "cpu")
+    same_arena = parallel.identical_on_all_ranks(parallel.arena_checksum(arena), "cpu")
+    if not same_arena:
+        raise SystemExit(f"rank {rank}: the weight arena differs between ranks after the broadcast")
+    # stands in for the per-rank golden decode of the real run: every rank checks something of its own and the passes are summed
+    passed = parallel.all_reduce_sum(1.0 if int(arena.numel()) > 0 and len(mine) > 0 else 0.0, "cpu")
+    if os.environ.get("SMOLTTS_BENCH_SLEEP_RANKS"):  # test hook of the launcher: ranks that outlive a signalled parent would show
+        time.sleep(float(os.environ["SMOLTTS_BENCH_SLEEP_RANKS"]))
     if rank == 0:
         print(json.dumps({"metric": "REHEARSAL of the N-rank launcher and collectives (gloo, CPU, no compute): not a measurement",
                           "value": None, "unit": "frames/s", "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup,
-                          "utterances_sharded": int(units), "arena_bytes": int(arena.numel()), "arena_identical_on_all_ranks": len(set(sums)) == 1,
+                          "utterances_sharded": int(units), "arena_bytes": int(arena.numel()), "arena_identical_on_all_ranks": same_arena,
+                          "parity": {"ranks_checked": world, "ranks_passed": int(passed), "arena_checksums_identical": same_arena},
                           "elapsed_s": round(elapsed, 4), "backend": "gloo"}), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -222,11 +262,12 @@ def run_rank(args) -> None:
     from smoltts_amd.tokenizer import load_tokenizer
 
     torch.set_num_threads(host_threads())
-    rank, world, local = parallel.init_distributed()
+    # SMOLTTS_BENCH_ONE_DEVICE: rehearsal of the N > 1 path on a 1-GPU box (with SMOLTTS_DIST_BACKEND=gloo);
+    # SMOLTTS_BENCH_PINNED: started by self_launch under a one-device HIP_VISIBLE_DEVICES mask -- either way the rank's GPU is device 0
+    one_dev = os.environ.get("SMOLTTS_BENCH_ONE_DEVICE") == "1" or os.environ.get("SMOLTTS_BENCH_PINNED") == "1"
+    rank, world, local = parallel.init_distributed(device_index=0 if one_dev else None)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if os.environ.get("SMOLTTS_BENCH_ONE_DEVICE") == "1":  # rehearsal of the N > 1 path on a 1-GPU box (with SMOLTTS_DIST_BACKEND=gloo)
-        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     load_library()
@@ -261,6 +302,10 @@ def run_rank(args) -> None:
         log(f"packed: LM arena {arena.numel() / 1e6:.1f} MB, Mimi arena {m_arena.numel() / 1e6:.1f} MB")
     arena, offsets = parallel.broadcast_weights(arena, offsets, dev)
     m_arena, m_offsets = parallel.broadcast_weights(m_arena, m_offsets, dev)
+    # every rank must hold the same bytes: checksums of both arenas, all-gathered and compared on every rank
+    arenas_same = parallel.identical_on_all_ranks(parallel.arena_checksum(arena) + parallel.arena_checksum(m_arena), dev)
+    if not arenas_same:
+        raise SystemExit(f"rank {rank}: the weight arenas differ between ranks after the broadcast")
     eng = LMEngine(cfg, None, tc, numerics, arena=arena, offsets=offsets)
     meng = MimiEngine(None, 8, window=0, arena=m_arena, offsets=m_offsets)
 
@@ -354,6 +399,9 @@ def run_rank(args) -> None:
             do_prefill(sessions[j], groups[j], stop_on_eos=False)
     torch.cuda.synchronize()
     prefill_ms = (time.perf_counter() - t0) * 1e3
+    for j in range(S):  # frames per graph launch: chosen here (and captured now), not by whichever decode call comes first
+        with torch.cuda.stream(streams[j]):
+            sessions[j].set_frames_per_graph(min(CH, 8))
     for j in range(S):
         with torch.cuda.stream(mimi_streams[j] if args.overlap_mimi else streams[j]):
             msessions[j].reset()
@@ -393,6 +441,29 @@ def run_rank(args) -> None:
     us_per_frame_step = elapsed / (K * CH) * 1e6
     L_mean = float(np.mean([p.shape[1] for p in mine])) + (W + K / 2) * CH  # mean context over the timed steps
 
+    # ---- every rank proves its own GPU on the committed golden grid (made with the reference model in the build container,
+    #      tests/golden/make_lm_goldens.py): prompt_0 of lm_150m.npz decoded for its 16 frames must equal grid_0 bit for bit.
+    #      No CPU oracle involved, so it runs on all ranks of an N > 1 job; the passes are summed over the backend.
+    golden_ok = None
+    gpath = ROOT / "tests" / "golden" / "lm_150m.npz"
+    if args.model == "smoltts_byte_150m" and args.weights == "bf16" and args.kv == "fp32" and gpath.exists():
+        g = np.load(gpath)
+        assert int(g["seed"]) == 0 and str(g["config_name"]) == args.model
+        gf = int(g["frames"])
+        gs = LMSession(eng, max_batch=1, max_seq=int(g["prompt_0"].shape[1]) + gf + 8, max_rows=int(g["prompt_0"].shape[1]), max_frames=gf)
+        with torch.cuda.stream(streams[0]):
+            gs.prefill([g["prompt_0"]], stop_on_eos=False)
+            gs.decode(gf - 1)
+        torch.cuda.synchronize()
+        gcodes, gn, _, _ = gs.fetch()
+        golden_ok = bool(int(gn[0]) == gf and np.array_equal(gcodes[0, :gf].T, g["grid_0"]))
+        gs.close()
+    ranks_checked = int(parallel.all_reduce_sum(0.0 if golden_ok is None else 1.0, dev))
+    ranks_passed = int(parallel.all_reduce_sum(1.0 if golden_ok else 0.0, dev))
+    rank_parity = {"ranks_checked": ranks_checked, "ranks_passed": ranks_passed, "arena_checksums_identical": arenas_same,
+                   "golden": "tests/golden/lm_150m.npz: prompt_0 decoded for 16 frames on every rank == grid_0 (ids bit-identical)" if ranks_checked else None}
+    log(f"golden grid on every rank: {ranks_passed} of {ranks_checked} ranks reproduce it; arenas identical on all ranks: {arenas_same}")
+
     # ---- dominant kernel in situ: replay the frame graph with every w1|w3 GEMM launch issued twice
     #      (idempotent), HIP events around the replays on the launch stream; the extra time per extra
     #      launch is the kernel's duration inside the real frame (cache state, neighbours and all)
@@ -403,7 +474,7 @@ def run_rank(args) -> None:
         def timed_frames(s_, n):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             with torch.cuda.stream(streams[0]):
-                s_.decode(1)  # (re)capture happens here, outside the events
+                s_.decode(n)  # both graphs (one frame, n frames) are (re)captured and warm here, outside the events
                 a.record(streams[0])
                 s_.decode(n)
                 b.record(streams[0])
@@ -413,13 +484,13 @@ def run_rank(args) -> None:
         torch.cuda.synchronize()
         # measure on a scratch session at the run's mean context so that the benchmarked sessions keep their frame budget
         ctx = int((W + K / 2) * CH)
-        scratch = LMSession(eng, max_batch=Bs, max_seq=max_T + ctx + 80, max_rows=sum(p.shape[1] for p in groups[0]), max_frames=ctx + 72,
+        scratch = LMSession(eng, max_batch=Bs, max_seq=max_T + ctx + 128, max_rows=sum(p.shape[1] for p in groups[0]), max_frames=ctx + 120,
                             kv_dtype=args.kv)
         with torch.cuda.stream(streams[0]):
             scratch.prefill(groups[0], stop_on_eos=False)
             scratch.decode(ctx)
         torch.cuda.synchronize()
-        base = min(timed_frames(scratch, 8) for _ in range(3))
+        base = min(timed_frames(scratch, 8) for _ in range(3))  # (6 x 16 frames in all: inside the scratch session's budget)
         scratch.measure_duplicate(EPI_SWIGLU, 2 * cfg.intermediate_size)  # this session only; its graphs are dropped
         dup = min(timed_frames(scratch, 8) for _ in range(3))
         scratch.measure_duplicate(-1)
@@ -657,11 +728,14 @@ def run_rank(args) -> None:
             "min_top2_margin": float(margin.min()),
             "first_audio_chunk": first_chunk, "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }
+        out["parity"] = dict(parity or {}, **rank_parity)
         print(json.dumps(out), flush=True)
     for x in msessions + sessions:
         x.close()
     if world > 1:
         torch.distributed.destroy_process_group()
+    if ranks_passed != ranks_checked:  # a rank whose GPU does not reproduce the golden grid: the line above says so, the run fails
+        raise SystemExit(f"rank {rank}: {ranks_checked - ranks_passed} rank(s) failed the golden-grid check")
 
 
 def main():

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SMOLTTS_ABI_VERSION 2
+#define SMOLTTS_ABI_VERSION 3
 
 enum {
   SMOLTTS_OK = 0,
@@ -173,8 +173,22 @@ int smoltts_lm_prefill_deferred(SmolttsSession* s, const int32_t* grid_dev, cons
  * column back (slow step at the slot's next position), then slow head + n_fast depth steps, all
  * greedy and on device; the frame loop is a captured hipGraph replayed n_frames times.  Slots that
  * are done (emitted <|im_end|> with stop_on_eos, reached max_frames, or filled their context: the next
- * token would land at position max_seq) are frozen. */
+ * token would land at position max_seq) are frozen.
+ *
+ * Host behaviour: the call queues graph launches on `stream` and returns, EXCEPT that the host never runs more than
+ * SMOLTTS_MAX_FRAMES_IN_FLIGHT frames (environment, read when the session is created; default 64, 0 = unbounded) ahead of
+ * the GPU: every half bound it records an event and, before queueing further, waits (hipEventSynchronize, blocking the
+ * calling thread) for the event of two groups ago.  One host thread that drives several sessions therefore overlaps them
+ * only up to that many frames each.  Frames go out `frames per graph` at a time where that many remain (see
+ * smoltts_session_set_frames_per_graph; SMOLTTS_FRAMES_PER_GRAPH overrides).  The library never inspects a profiler's
+ * environment: a counter-collecting profiler run sets SMOLTTS_MAX_FRAMES_IN_FLIGHT=2 SMOLTTS_FRAMES_PER_GRAPH=1 itself
+ * (tools/collect_pmc.sh). */
 int smoltts_lm_decode(SmolttsSession* s, int32_t n_frames, void* stream);
+
+/* Frames captured into one multi-frame graph of this session: n = 1 single-frame graphs only, 2..16 that many, 0 = follow
+ * the decode calls (min(n_frames, 8) of the largest call so far -- the default).  Called after a prefill with n > 0 it also
+ * captures the graphs now (on `stream`), so that the first decode call of a request does not pay the capture. */
+int smoltts_session_set_frames_per_graph(SmolttsSession* s, int32_t n, void* stream);
 
 /* Sampling mode (reference GenerationSettings, lm/generate.py:12-16): temp / fast_temp <= 0 select
  * greedy argmax for the slow / depth tokens (the default), otherwise exact categorical sampling from

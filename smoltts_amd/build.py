@@ -27,7 +27,8 @@ SOURCES = ["api.hip", "gemm.hip", "gemm_b3.hip", "gemm3.hip", "attention.hip", "
            "seanet.hip", "seanet_last.hip", "conv_xs.hip"]
 ARCH = "gfx950"
 PRODUCT_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
-NAMED_VARIANTS = {"hooks": ["-DSMOLTTS_DEBUG_HOOKS"]}  # event hooks + in-kernel cycle stamps for tools/
+NAMED_VARIANTS = {"hooks": ["-DSMOLTTS_DEBUG_HOOKS"],  # event hooks + in-kernel cycle stamps for tools/
+                  "knobs": ["-DSMOLTTS_DBG_KNOBS"]}    # the experiment environment switches of tools/ (forced tiles, kernels off)
 
 
 def _hipcc() -> str:

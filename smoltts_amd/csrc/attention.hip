@@ -468,7 +468,8 @@ int launch_attention(const float* q, const void* kc, const void* vc, const int32
     ST_CHECK_HIP(hipGetLastError());
     return SMOLTTS_OK;
   }
-  if ((long)n_rows * n_kv_heads >= 1024 && getenv("SMOLTTS_NO_MFMA_ATTN") == nullptr) {  // prompt prefill, codec transformer
+  static const bool no_mfma_attn = ST_KNOB_INT("SMOLTTS_NO_MFMA_ATTN", 0) != 0;  // experiments (knobs builds only)
+  if ((long)n_rows * n_kv_heads >= 1024 && !no_mfma_attn) {  // prompt prefill, codec transformer
     // one query head per wave: the longest row tile (the critical path of the launch) is G times shorter, and the K / V
     // tiles re-read by the G waves of a kv group come from L2
     const int nx = (n_rows + 15) / 16, units = ((nx + 3) / 4) * n_kv_heads, members = 4 * (n_q_heads / n_kv_heads);

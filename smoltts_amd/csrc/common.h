@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 #include <string>
@@ -37,6 +38,34 @@ void set_error(const char* fmt, ...);
     int _r = (expr);                                                                      \
     if (_r != SMOLTTS_OK) return _r;                                                      \
   } while (0)
+
+// Per-device "first time" flags of the launchers: a kernel's MaxDynamicSharedMemorySize attribute and the CU count are
+// properties of a DEVICE, so a process that moves to a second GPU must set / read them again there.
+struct PerDevice {
+  static constexpr int kMax = 64;
+  unsigned long long done_mask = 0;   // bit d: done on device d (launchers run on the caller's thread; races only repeat the call)
+  int value[kMax] = {0};
+  static int current() { int d = 0; (void)hipGetDevice(&d); return d < 0 ? 0 : (d >= kMax ? kMax - 1 : d); }
+  bool first_time(int dev) { const unsigned long long bit = 1ull << dev; const bool first = !(done_mask & bit); done_mask |= bit; return first; }
+};
+inline int device_cu_count() {  // CUs of the current device (cached per device)
+  static PerDevice cache;
+  const int d = PerDevice::current();
+  if (cache.first_time(d)) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+    cache.value[d] = n;
+  }
+  return cache.value[d];
+}
+
+// Experiment switches of tools/ (forced tile shapes, kernels switched off) exist only in builds with -DSMOLTTS_DBG_KNOBS
+// (python -m smoltts_amd.build --variant knobs): the product library reads no such environment variable.
+#ifdef SMOLTTS_DBG_KNOBS
+#define ST_KNOB_INT(name, dflt) ([] { const char* e_ = getenv(name); return e_ ? atoi(e_) : (dflt); }())
+#else
+#define ST_KNOB_INT(name, dflt) (dflt)
+#endif
 
 // ---- device helpers
 __device__ __forceinline__ float bf16_lo(uint32_t dw) { return __uint_as_float(dw << 16); }

@@ -196,10 +196,11 @@ __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
 template <int NTW, int MT, int RA, int EPI>
 int launch_xs(const GemmDev& g, int nsplit, hipStream_t stream) {
   const size_t lds = (size_t)3 * (g.cpt * 4) * RA * 16 + (g.ln_w ? (32 * 64 + 64) * sizeof(float) : 0);
-  static size_t attr = 0;
-  if (lds > attr) {  // > 64 KB of dynamic LDS must be requested per kernel
+  static PerDevice attr;  // value[d] = the largest size requested on device d so far
+  const int dev = PerDevice::current();
+  if (attr.first_time(dev) || (int)lds > attr.value[dev]) {  // > 64 KB of dynamic LDS must be requested per kernel and device
     ST_CHECK_HIP(hipFuncSetAttribute((const void*)conv_xs_kernel<NTW, MT, RA, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = lds;
+    attr.value[dev] = (int)lds;
   }
   const int T = g.rows_per_batch > 0 ? g.rows_per_batch : g.M;
   const dim3 grid((T + 16 * MT - 1) / (16 * MT), g.M / T, nsplit);
@@ -235,8 +236,8 @@ int linear_ntw(const GemmDev& d, int epilogue) {
 // residual: 20.6 -> 13.4 us) and fc1 (N = 2048, GELU: 38 -> 33 us); the k1 convs that end the resnet blocks of stages 1 and 2
 // (K = 256 / 128 -> N = 512 / 256, + residual, per-slot rows).
 bool conv_xs_applies(const GemmDev& d, int epilogue) {
-  static const bool off = [] { const char* e = getenv("SMOLTTS_CONV_XS"); return e && atoi(e) == 0; }();  // experiments
-  static const bool lin_off = [] { const char* e = getenv("SMOLTTS_LINEAR_XS"); return e && atoi(e) == 0; }();
+  static const bool off = ST_KNOB_INT("SMOLTTS_CONV_XS", 1) == 0;  // experiments (knobs builds only)
+  static const bool lin_off = ST_KNOB_INT("SMOLTTS_LINEAR_XS", 1) == 0;
   if (off || !d.w3) return false;
   if (d.x_bstride % 4 != 0 || d.ldo % 4 != 0 || d.o_bstride % 4 != 0 || d.ldx % 4 != 0) return false;
   if (d.ldx >= d.K && linear_ksplit(d, epilogue)) {

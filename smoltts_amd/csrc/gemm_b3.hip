@@ -162,8 +162,8 @@ template <int EPI>
 static int launch_b3_epi(const GemmDev& d, hipStream_t stream) {
   auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
   GemmDev g = d;
-  static const int env_taps = [] { const char* e = getenv("SMOLTTS_B3_TAPS"); return e ? atoi(e) : 1; }();  // experiments: 0 = K order
-  static const int env_xcd = [] { const char* e = getenv("SMOLTTS_B3_XCD"); return e ? atoi(e) : -1; }();   // experiments: 0 rows | 1 columns
+  static const int env_taps = ST_KNOB_INT("SMOLTTS_B3_TAPS", 1);  // experiments (knobs builds only): 0 = K order
+  static const int env_xcd = ST_KNOB_INT("SMOLTTS_B3_XCD", -1);   // experiments: 0 rows | 1 columns
   g.taps = 1; g.cpt = d.K >> 5;
   if (env_taps && d.ldx < d.K && d.ldx % 32 == 0 && d.K % d.ldx == 0) { g.taps = (int)(d.K / d.ldx); g.cpt = (int)(d.ldx >> 5); }
   const double x_bytes = 4.0 * d.M * (d.ldx < d.K ? d.ldx : d.K), w_bytes = 6.0 * d.N * d.K;
@@ -189,7 +189,7 @@ static int launch_b3_epi(const GemmDev& d, hipStream_t stream) {
     ST_CHECK_HIP(hipGetLastError());
     return SMOLTTS_OK;
   }
-  static const int force = [] { const char* e = getenv("SMOLTTS_B3_TILE"); return e ? atoi(e) : 0; }();  // experiments: 44 | 42 | 22
+  static const int force = ST_KNOB_INT("SMOLTTS_B3_TILE", 0);  // experiments (knobs builds only): 44 | 42 | 22
   if (force == 44 || (force == 0 && blocks(128, 128) >= 512 && d.N >= 128)) {
     const dim3 grid = grid1d(128, 128);
     hipLaunchKernelGGL((gemm_b3_kernel<4, 4, EPI>), grid, dim3(256), 0, stream, g);

@@ -68,7 +68,10 @@ struct SmolttsSession {
   hipGraphExec_t multi_exec;   // `multi_frames` consecutive decode frames in one graph (fewer graph launches per tick / chunk)
   bool multi_ready;
   int flight_limit;            // SMOLTTS_MAX_FRAMES_IN_FLIGHT as read at creation (0 = unbounded)
-  int multi_frames;            // SMOLTTS_FRAMES_PER_GRAPH (1 = single-frame graphs only); default: the first multi-frame call's count, at most 8
+  int multi_frames;            // frames per multi-frame graph (1 = single-frame graphs only): SMOLTTS_FRAMES_PER_GRAPH, else
+                               // smoltts_session_set_frames_per_graph, else min(n_frames, 8) of the largest decode call so far
+  bool multi_fixed;            // set by the environment or the API: decode calls do not change it
+  bool multi_env;              // set by SMOLTTS_FRAMES_PER_GRAPH: the API does not change it either
   bool prefilled;
   // bounded run-ahead of the host over the GPU (smoltts_lm_decode): an event every `flight_group` frame graphs, the host
   // waits for the one recorded two groups ago before it launches further
@@ -489,6 +492,23 @@ bool graphs_enabled() {
   return !(no_graph && no_graph[0] == '1');
 }
 
+int run_decode_frame(SmolttsSession* s, hipStream_t st);
+
+// The graph of `multi_frames` consecutive frames (every graph launch costs the GPU a gap between the last node of one graph and
+// the first of the next); a graph of several frames is that many frames queued at once, so it stays inside the run-ahead bound.
+int ensure_multi_graph(SmolttsSession* s, int n_frames, hipStream_t st) {
+  if (s->flight_limit > 0 && s->multi_frames > s->flight_limit) s->multi_frames = s->flight_limit;
+  const int mf = s->multi_frames;
+  if (mf > 1 && n_frames >= mf && !s->multi_ready) {
+    ST_TRY(capture_graph(st, &s->multi_exec, [&](hipStream_t cap) {
+      for (int i = 0; i < mf; ++i) ST_TRY(run_decode_frame(s, cap));
+      return (int)SMOLTTS_OK;
+    }));
+    s->multi_ready = true;
+  }
+  return SMOLTTS_OK;
+}
+
 int check_offsets(const SmolttsLMConfig& c, const SmolttsLMWeights& w, size_t bytes) {
   auto ok = [&](uint64_t off, size_t need) { return off % 16 == 0 && off + need <= bytes; };
   ST_REQUIRE(c.weight_format == SMOLTTS_W_BF16 || c.weight_format == SMOLTTS_W_FP8, SMOLTTS_E_INVALID,
@@ -611,19 +631,18 @@ int smoltts_session_create_kv(SmolttsEngine* e, void* slab_dev, size_t slab_byte
       return SMOLTTS_E_HIP;
     }
   }
-  {  // frames the host may run ahead of the GPU: SMOLTTS_MAX_FRAMES_IN_FLIGHT (default 16; 0 = unbounded)
+  {  // frames the host may run ahead of the GPU: SMOLTTS_MAX_FRAMES_IN_FLIGHT (default 64; 0 = unbounded).  A profiler that
+     // rewrites every dispatch into several packets (rocprofv3 --pmc) needs a small bound and one frame per graph: its
+     // command line sets both variables explicitly (tools/collect_pmc.sh) -- the library itself never looks for a profiler.
     const char* lim = getenv("SMOLTTS_MAX_FRAMES_IN_FLIGHT");
-    // under `rocprofv3 --pmc` (it exports ROCPROF_COUNTERS to the profiled process) every dispatch becomes several packets of the
-    // profiler's intercept queue, which does not survive thousands of them queued at once: 2 frames ahead, one frame per graph
-    const char* pmc = getenv("ROCPROF_COUNTERS");
-    const bool counters = pmc && *pmc;
-    const int limit = lim ? atoi(lim) : (counters ? 2 : 16);
+    const int limit = lim ? atoi(lim) : 64;
     s->flight_group = limit > 0 ? (limit + 1) / 2 : 0;
     for (int k = 0; k < 2; ++k)
       if (hipEventCreateWithFlags(&s->flight_ev[k], hipEventDisableTiming) != hipSuccess) s->flight_group = 0;
     const char* fpg = getenv("SMOLTTS_FRAMES_PER_GRAPH");  // frames captured into one graph where that many remain to be launched
-    s->multi_frames = fpg ? atoi(fpg) : (counters ? 1 : 0);  // 0: chosen by the first call that asks for several frames (min(n, 8))
+    s->multi_frames = fpg ? atoi(fpg) : 0;  // 0: follows the calls (smoltts_session_set_frames_per_graph, or min(n_frames, 8) of the largest call so far)
     if (s->multi_frames < 0 || s->multi_frames > 16) s->multi_frames = 1;
+    s->multi_fixed = s->multi_env = fpg != nullptr;
     s->flight_limit = limit;
   }
   hipLaunchKernelGGL(init_state_kernel, dim3((max_batch + 63) / 64), dim3(64), 0, 0, max_batch, e->cfg.n_fast, s->iota,
@@ -763,17 +782,15 @@ int smoltts_lm_decode(SmolttsSession* s, int32_t n_frames, void* stream) {
   // more, waits for the event of two groups ago -- the GPU queue never drains, the host merely stops piling up packets.
   // Frames are launched `multi_frames` at a time where that many remain: every graph launch costs the GPU a gap between the
   // last node of one graph and the first of the next (measured: the frame rate of a 32-frame chunk rises by the gaps saved).
-  if (s->multi_frames == 0 && n_frames >= 2) s->multi_frames = n_frames < 8 ? n_frames : 8;  // a serving tick / a bench chunk
-  // (a graph of several frames is that many frames queued at once: it stays inside the run-ahead bound, see below)
-  if (s->flight_limit > 0 && s->multi_frames > s->flight_limit) s->multi_frames = s->flight_limit;
-  const int mf = s->multi_frames;
-  if (mf > 1 && n_frames >= mf && !s->multi_ready) {
-    ST_TRY(capture_graph(st, &s->multi_exec, [&](hipStream_t cap) {
-      for (int i = 0; i < mf; ++i) ST_TRY(run_decode_frame(s, cap));
-      return (int)SMOLTTS_OK;
-    }));
-    s->multi_ready = true;
+  if (!s->multi_fixed && n_frames >= 2) {  // follows the calls: a later, longer call (a tick after a 2-frame warm-up) re-captures
+    const int want = n_frames < 8 ? n_frames : 8;
+    if (want > s->multi_frames) {
+      s->multi_frames = want;
+      if (s->multi_ready) { (void)hipGraphExecDestroy(s->multi_exec); s->multi_ready = false; }
+    }
   }
+  ST_TRY(ensure_multi_graph(s, n_frames, st));
+  const int mf = s->multi_ready ? s->multi_frames : 1;
   for (int f = 0; f < n_frames;) {
     if (s->flight_group > 0 && s->flight_count >= s->flight_group) {
       const int k = s->flight_cur;
@@ -822,6 +839,26 @@ int smoltts_session_measure_duplicate(SmolttsSession* s, int32_t code, int32_t n
 int smoltts_session_drop_graph(SmolttsSession* s) {
   ST_REQUIRE(s, SMOLTTS_E_INVALID, "session_drop_graph: null session");
   drop_graphs(s);
+  return SMOLTTS_OK;
+}
+
+// Frames per multi-frame graph of this session (1 = single-frame graphs only, 0 = follow the decode calls again); with a
+// stream and after a prefill, the graphs are captured here (a warm-up step) instead of inside the first decode call.
+int smoltts_session_set_frames_per_graph(SmolttsSession* s, int32_t n, void* stream) {
+  ST_REQUIRE(s, SMOLTTS_E_INVALID, "session_set_frames_per_graph: null session");
+  ST_REQUIRE(n >= 0 && n <= 16, SMOLTTS_E_INVALID, "session_set_frames_per_graph: %d frames per graph (0..16)", n);
+  if (s->multi_env) n = s->multi_frames;  // SMOLTTS_FRAMES_PER_GRAPH wins (a profiler run pins one frame per graph)
+  if (n != s->multi_frames && s->multi_ready) { (void)hipGraphExecDestroy(s->multi_exec); s->multi_ready = false; }
+  s->multi_frames = n;
+  s->multi_fixed = n > 0;
+  if (n > 0 && s->prefilled && graphs_enabled()) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!s->graph_ready) {
+      ST_TRY(capture_graph(st, &s->graph_exec, [&](hipStream_t cap) { return run_decode_frame(s, cap); }));
+      s->graph_ready = true;
+    }
+    ST_TRY(ensure_multi_graph(s, n, st));
+  }
   return SMOLTTS_OK;
 }
 

@@ -383,20 +383,14 @@ int launch_seanet_last(const MimiLastStageArgs& a, hipStream_t st) {
   ST_REQUIRE(a.in && a.wt && a.bt && a.w2 && a.b2 && a.w3 && a.b3 && a.final_w && a.pcm && a.slot_pos && a.T > 0 && a.batch > 0,
              SMOLTTS_E_INVALID, "seanet last stage: null or empty argument");
   ST_REQUIRE(a.batch <= 65535, SMOLTTS_E_INVALID, "seanet last stage: batch too large");
-  static bool attr_set = false;
-  if (!attr_set) {  // > 64 KB of dynamic LDS must be requested once per kernel
+  static PerDevice attr;
+  if (attr.first_time(PerDevice::current()))  // > 64 KB of dynamic LDS must be requested once per kernel and device
     ST_CHECK_HIP(hipFuncSetAttribute((const void*)seanet_last_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    attr_set = true;
-  }
   const int tiles_per_slot = (a.T + S - 2) / (S - 1);
   ST_REQUIRE((long)tiles_per_slot * a.batch < (1L << 30), SMOLTTS_E_INVALID, "seanet last stage: too many rows for one launch");
   LastDev d{a.in, (long)a.in_bstride, a.T, (const char*)a.wt, a.bt, (const char*)a.w2, a.b2, (const char*)a.w3, a.b3,
             a.final_w, a.final_b, a.pcm, (long)a.pcm_stride, a.slot_pos, tiles_per_slot, tiles_per_slot * a.batch};
-  static const int n_cu = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    return n;
-  }();
+  const int n_cu = device_cu_count();
   const dim3 grid(d.n_tiles < n_cu ? d.n_tiles : n_cu);  // persistent: the LDS footprint admits exactly one workgroup per CU
   hipLaunchKernelGGL(seanet_last_kernel, grid, dim3(512), LDS_BYTES, st, d);
   ST_CHECK_HIP(hipGetLastError());

@@ -104,7 +104,7 @@ _EXPORTS = [
     "smoltts_mimi_slab_bytes", "smoltts_mimi_session_create", "smoltts_mimi_session_destroy", "smoltts_mimi_reset",
     "smoltts_mimi_decode_chunk", "smoltts_k_gemm", "smoltts_k_attention", "smoltts_k_embed", "smoltts_k_argmax",
     "smoltts_k_layernorm", "smoltts_k_gemm3", "smoltts_k_x3_pack",
-    "smoltts_session_measure_duplicate", "smoltts_session_margin_at", "smoltts_session_drop_graph",
+    "smoltts_session_measure_duplicate", "smoltts_session_margin_at", "smoltts_session_drop_graph", "smoltts_session_set_frames_per_graph",
     "smoltts_session_slab_bytes_kv", "smoltts_session_create_kv", "smoltts_k_attention_kv", "smoltts_session_set_sampling", "smoltts_k_sample",
     "smoltts_lm_prefill_chunk", "smoltts_lm_prefill_deferred", "smoltts_mimi_reset_slots", "smoltts_mimi_encoder_create", "smoltts_mimi_encoder_destroy", "smoltts_mimi_encode_frames",
     "smoltts_mimi_encode_workspace_bytes", "smoltts_mimi_encode",
@@ -167,6 +167,7 @@ def load_library(path: Optional[Path] = None):
     lib.smoltts_session_measure_duplicate.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.smoltts_session_margin_at.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     lib.smoltts_session_drop_graph.argtypes = [C.c_void_p]
+    lib.smoltts_session_set_frames_per_graph.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.smoltts_mimi_reset_slots.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.smoltts_lm_prefill_deferred.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                                 C.c_int32, C.c_void_p]
@@ -184,7 +185,7 @@ def load_library(path: Optional[Path] = None):
     if hasattr(lib, "smoltts_profile_begin"):  # diagnostic builds only (-DSMOLTTS_DEBUG_HOOKS)
         lib.smoltts_profile_begin.argtypes = [C.c_int32] * 4
         lib.smoltts_profile_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
-    if lib.smoltts_abi_version() != 2:
+    if lib.smoltts_abi_version() != 3:
         raise SmolttsError("libsmoltts_hip.so ABI version mismatch")
     if path is None:
         _lib = lib
@@ -455,6 +456,11 @@ class LMSession:
 
     def decode(self, n_frames: int) -> None:
         check(self.lib.smoltts_lm_decode(self.handle, int(n_frames), current_stream_ptr()), "smoltts_lm_decode")
+
+    def set_frames_per_graph(self, n: int) -> None:
+        """Frames per multi-frame graph (1 = single-frame graphs, 0 = follow the decode calls).  After a prefill and with
+        n > 0 the graphs are captured now, on the current stream, instead of inside the first decode call."""
+        check(self.lib.smoltts_session_set_frames_per_graph(self.handle, int(n), current_stream_ptr()), "smoltts_session_set_frames_per_graph")
 
     def fetch(self):
         """Synchronise and return (codes [B, max_frames, H] int32, n_frames [B], done [B], margin [B]) on the host."""

@@ -20,8 +20,12 @@ def dist_env() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 
 
-def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
+def init_distributed(backend: Optional[str] = None, device_index: Optional[int] = None) -> Tuple[int, int, int]:
+    """``device_index``: the GPU this rank uses when it is not LOCAL_RANK (a rank started under a one-device
+    HIP_VISIBLE_DEVICES mask uses device 0); returned in place of LOCAL_RANK."""
     rank, world, local = dist_env()
+    if device_index is not None:
+        local = device_index
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -54,6 +58,31 @@ def broadcast_weights(arena: Optional[torch.Tensor], offsets, device, src: int =
     buf = arena.to(device) if rank == src else torch.empty(nbytes, dtype=torch.uint8, device=device)
     dist.broadcast(buf, src=src)
     return buf, offsets
+
+
+def arena_checksum(arena: torch.Tensor) -> Tuple[float, float, float]:
+    """Three order-sensitive-enough sums of a packed byte arena, each exact in float64 (they travel through the float
+    all-gather): the byte sum and two 20-bit fields of its int32 words.  Computed where the arena lives, in pieces."""
+    a = arena.reshape(-1)
+    n4 = (a.numel() // 4) * 4
+    s0 = s1 = s2 = 0
+    step = 1 << 26  # bytes per piece: bounds the int64 temporaries
+    for i in range(0, a.numel(), step):
+        s0 += int(a[i:i + step].to(torch.int64).sum())
+    for i in range(0, n4, step):
+        w = a[i:min(i + step, n4)].view(torch.int32).to(torch.int64)
+        s1 += int((w & 0xFFFFF).sum())
+        s2 += int(((w >> 12) & 0xFFFFF).sum())
+    return float(s0), float(s1), float(s2)
+
+
+def identical_on_all_ranks(values: Sequence[float], device) -> bool:
+    """True when every rank holds the same tuple of numbers (e.g. ``arena_checksum``): all-gathered and compared on every rank."""
+    ok = True
+    for v in values:
+        got = all_gather_floats(float(v), device)
+        ok = ok and len(set(got)) == 1
+    return ok
 
 
 def _reduce_device(device):

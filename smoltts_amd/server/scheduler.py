@@ -78,6 +78,7 @@ class BatchScheduler:
         self.session = LMSession(tts.lm, max_batch, max_seq=tts.config.max_seq_len, max_rows=max(max_prompt_rows, max_batch),
                                  max_frames=self.max_frames)
         _apply_sampling(self.session, self.settings)
+        self.session.set_frames_per_graph(min(max(frames_per_tick, 1), 8))  # a tick is one graph launch where it fits
         self._torch = torch
         self._pending: "queue.Queue[_Request]" = queue.Queue()
         self._active: Dict[int, _Request] = {}

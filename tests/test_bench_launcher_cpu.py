@@ -30,6 +30,9 @@ def test_bench_self_launches_two_ranks_and_reports_ranks_seen():
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2                 # the all-reduce of ones saw both ranks
     assert d["utterances_sharded"] == 6 and d["arena_identical_on_all_ranks"] is True and d["arena_bytes"] > 0
     assert d["value"] is None and "REHEARSAL" in d["metric"]         # never mistaken for a measurement
+    # the per-rank self-check plumbing of the N > 1 run: arena checksums all-gathered and compared on every rank, every
+    # rank's own check summed over the backend (in the real run: the golden grid decoded on each rank's GPU)
+    assert d["parity"] == {"ranks_checked": 2, "ranks_passed": 2, "arena_checksums_identical": True}
 
 
 def test_a_failing_rank_ends_the_run_with_its_exit_code():
@@ -49,3 +52,33 @@ def test_under_an_external_launcher_the_process_is_a_rank():
     assert d["n_gpus"] == 1 and d["ranks_seen"] == 1
     r, _ = _run({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "2", "--rehearse-launcher")
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr          # mismatch is an error, not a silent 1-rank run
+
+
+def test_a_signal_to_the_launcher_takes_the_ranks_down():
+    """SIGTERM to the parent (a driver's `timeout`): the ranks run in sessions of their own, so the parent must end them
+    itself -- none may survive it holding a GPU."""
+    import signal
+
+    env = dict(os.environ, TORCH_COMPILE_DISABLE="1", SMOLTTS_BENCH_SLEEP_RANKS="120")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--rehearse-launcher"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        deadline = time.time() + 120
+        kids = []
+        while time.time() < deadline and len(kids) < 2:  # the children of the launcher, by parent PID
+            time.sleep(0.5)
+            out = subprocess.run(["ps", "-o", "pid=", "--ppid", str(p.pid)], capture_output=True, text=True).stdout.split()
+            kids = [int(x) for x in out]
+        assert len(kids) == 2, kids
+        time.sleep(1.0)
+        p.send_signal(signal.SIGTERM)
+        rc = p.wait(timeout=60)
+        assert rc == 128 + signal.SIGTERM
+        time.sleep(0.5)
+        for k in kids:
+            assert not Path(f"/proc/{k}").exists() or "Z" in Path(f"/proc/{k}/stat").read_text().split()[2], f"rank process {k} survived the launcher"
+    finally:
+        if p.poll() is None:
+            p.kill()

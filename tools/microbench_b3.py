@@ -5,8 +5,14 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch  # noqa: E402
 
+import os  # noqa: E402
+
 from smoltts_amd import engine as E, ops  # noqa: E402
 
+if any(k in os.environ for k in ("SMOLTTS_B3_TILE", "SMOLTTS_B3_TAPS", "SMOLTTS_B3_XCD", "SMOLTTS_CONV_XS", "SMOLTTS_LINEAR_XS")):
+    from smoltts_amd.build import build_library  # the experiment switches exist only in the `knobs` variant
+
+    os.environ["SMOLTTS_LIB"] = str(build_library(variant="knobs"))
 E.load_library()
 shapes = [("conv0", 2048, 1024, 3584), ("convT1", 2048, 4096, 2048), ("res1.c3", 16384, 256, 1536), ("res1.c1", 16384, 512, 256),
           ("convT2", 16384, 1536, 1024), ("res2.c3", 98304, 128, 768), ("res2.c1", 98304, 256, 128), ("convT3", 98304, 640, 512),
