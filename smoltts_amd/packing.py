@@ -128,8 +128,47 @@ def rope_table(n_pos: int, head_dim: int, base: float, bf16: bool) -> torch.Tens
     return cache.float().contiguous()
 
 
-def _clean(state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-    return {k.replace("_orig_mod.", ""): v for k, v in state.items()}
+class _Reads(dict):
+    """A state dict that remembers which keys a packer read (``report["unused"]``: the keys it did not)."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.read = set()
+
+    def __getitem__(self, k):
+        self.read.add(k)
+        return super().__getitem__(k)
+
+    def unused(self) -> List[str]:
+        return sorted(k for k in self if k not in self.read)
+
+
+def _clean(state: Dict[str, torch.Tensor]) -> "_Reads":
+    return _Reads({k.replace("_orig_mod.", ""): v for k, v in state.items()})
+
+
+# Keys of the Hugging Face ``kyutai/mimi`` state dict (transformers.MimiModel) that neither half of the codec reads, and why.
+MIMI_IGNORED = (
+    (".codebook.initialized", "training bookkeeping of the k-means initialisation (codec/rvq.py never reads it)"),
+    ("quantizer.acoustic_residual_vector_quantizer.layers.", "acoustic codebooks beyond the num_codebooks - 1 the model emits (31 stored, 7 used: codec/rvq.py:118-131)"),
+)
+
+
+def classify_mimi_keys(state: Dict[str, torch.Tensor], num_codebooks: int = 8) -> Dict[str, object]:
+    """Which keys of a ``kyutai/mimi`` checkpoint the decoder packer reads, which the encoder packer reads, which are
+    ignored on purpose (with the reason) and which are unknown (must be empty for a checkpoint this package understands)."""
+    rd, re_ = {}, {}
+    pack_mimi(state, num_codebooks, max_positions=64, report=rd)
+    pack_mimi_encoder(state, num_codebooks, max_positions=64, report=re_)
+    dec, enc = set(state) - set(rd["unused"]), set(state) - set(re_["unused"])
+    ignored, unknown = {}, []
+    for k in sorted(set(state) - dec - enc):
+        why = next((w for pat, w in MIMI_IGNORED if (k.endswith(pat) if pat.startswith(".") else k.startswith(pat))), None)
+        if why is None:
+            unknown.append(k)
+        else:
+            ignored[k] = why
+    return {"decoder": sorted(dec), "encoder": sorted(enc), "ignored": ignored, "unknown": unknown}
 
 
 def _wqkv(st, prefix):
@@ -161,9 +200,11 @@ def fp8_reference_state(cfg: RQTransformerModelArgs, state: Dict[str, torch.Tens
     return dataclasses.replace(cfg, tie_word_embeddings=False), out
 
 
-def pack_lm(cfg: RQTransformerModelArgs, state: Dict[str, torch.Tensor], numerics: NumericsMode, weight_format: str = "bf16"):
+def pack_lm(cfg: RQTransformerModelArgs, state: Dict[str, torch.Tensor], numerics: NumericsMode, weight_format: str = "bf16",
+            report: Dict[str, object] = None):
     """-> (arena uint8 CPU tensor, offsets dict).  Embedding tables are bf16; the Linears are bf16 T16x32
-    tiles, or with ``weight_format="fp8"`` e4m3 tiles + per-row scales (``fp8_block``)."""
+    tiles, or with ``weight_format="fp8"`` e4m3 tiles + per-row scales (``fp8_block``).  Tensors may be stored in any
+    float dtype (bf16 checkpoints, fp32 trainer states).  ``report`` (a dict) receives ``unused``: keys nothing read."""
     if weight_format not in ("bf16", "fp8"):
         raise ValueError(weight_format)
     st = _clean(state)
@@ -222,6 +263,8 @@ def pack_lm(cfg: RQTransformerModelArgs, state: Dict[str, torch.Tensor], numeric
     off["fast_rope"] = ab.add(rope_table(n_fast, cfg.fast_head_dim, cfg.rope_base, numerics.rope_bf16))
     off["layers"] = [block(f"layers.{i}.") for i in range(cfg.n_layer)]
     off["fast_layers"] = [block(f"fast_layers.{i}.") for i in range(cfg.n_fast_layer)]
+    if report is not None:
+        report["unused"] = st.unused()
     return ab.finish(), off
 
 
@@ -272,8 +315,8 @@ def mimi_conv_specs():
     return specs
 
 
-def pack_mimi(state: Dict[str, torch.Tensor], num_codebooks: int = 8, max_positions: int = 4096):
-    st = {k: v.float() for k, v in state.items()}
+def pack_mimi(state: Dict[str, torch.Tensor], num_codebooks: int = 8, max_positions: int = 4096, report: Dict[str, object] = None):
+    st = _Reads({k: v.float() for k, v in state.items()})
     ab = ArenaBuilder()
     f32 = torch.float32
     off: Dict[str, object] = {}
@@ -325,6 +368,8 @@ def pack_mimi(state: Dict[str, torch.Tensor], num_codebooks: int = 8, max_positi
     off["final_w"] = ab.add(fw.reshape(-1).contiguous())
     off["n_layers"] = n_layers
     off["max_positions"] = max_positions
+    if report is not None:
+        report["unused"] = st.unused()
     return ab.finish(), off
 
 
@@ -345,10 +390,10 @@ def mimi_encoder_conv_specs():
     return specs
 
 
-def pack_mimi_encoder(state: Dict[str, torch.Tensor], num_codebooks: int = 8, max_positions: int = 2048):
+def pack_mimi_encoder(state: Dict[str, torch.Tensor], num_codebooks: int = 8, max_positions: int = 2048, report: Dict[str, object] = None):
     """Arena + offsets (SmolttsMimiEncWeights) of the encode half; ``state`` uses the Hugging Face
     ``MimiModel.state_dict()`` names (encoder.*, encoder_transformer.*, downsample.*, quantizer.*)."""
-    st = {k: v.float() for k, v in state.items()}
+    st = _Reads({k: v.float() for k, v in state.items()})
     ab = ArenaBuilder()
     f32 = torch.float32
     off: Dict[str, object] = {}
@@ -398,4 +443,6 @@ def pack_mimi_encoder(state: Dict[str, torch.Tensor], num_codebooks: int = 8, ma
     off["n_layers"] = n_layers
     off["max_positions"] = max_positions
     off["num_codebooks"] = num_codebooks
+    if report is not None:
+        report["unused"] = st.unused()
     return ab.finish(), off

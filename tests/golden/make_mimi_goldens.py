@@ -4,8 +4,9 @@ The Mimi arithmetic of the reference lives in third-party code: the MLX port und
 mlx_inference/src/smoltts_mlx/codec/ (not importable: no `mlx`) mirrors `transformers.MimiModel`
 (used by the reference's data_pipeline/utils/codec.py:4,19).  This script loads our seeded
 synthetic decoder-side weights into `transformers.MimiModel`, decodes seeded codes with it and
-stores (seed, codes, pcm) as data.  tests/test_mimi_oracle.py checks oracle/mimi_oracle.py against
-both the live third-party model and these vectors.
+stores (seed, codes, pcm) as data.  tests/test_oracle_cpu.py checks oracle/mimi_oracle.py against
+both the live third-party model and these vectors; tests/test_round2_gpu.py and tests/test_mimi_gpu.py decode them on
+the HIP engine (also replicated to the benchmark's chunk size).
 
 Usage: python tests/golden/make_mimi_goldens.py
 """

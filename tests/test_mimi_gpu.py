@@ -91,22 +91,83 @@ def test_capacity_error(mimi):
 
 def test_long_chunks_are_decoded_in_pieces():
     """batch * frames * 1920 rows beyond one launch's grid: smoltts_mimi_decode_chunk cuts the chunk into pieces, which
-    the streaming state makes equivalent to separate calls."""
+    the streaming state makes equivalent to separate calls -- and both equal the oracle (three of the slots are decoded
+    on the CPU: first, middle, last)."""
+    from oracle.mimi_oracle import MimiDecodeOracle
     from smoltts_amd.codec.synthetic import synthetic_mimi_state
     from smoltts_amd.engine import MimiEngine, MimiSession
 
-    eng = MimiEngine(synthetic_mimi_state(seed=1), 8, max_positions=700)
+    st = synthetic_mimi_state(seed=1)
+    eng = MimiEngine(st, 8, max_positions=700)
     B, F = 8, 280  # 8 * 280 * 1920 = 4.3 M rows > 4 M
     g = torch.Generator().manual_seed(0)
-    codes = torch.randint(0, 2048, (B, F, 8), generator=g, dtype=torch.int32).cuda()
+    codes = torch.randint(0, 2048, (B, F, 8), generator=g, dtype=torch.int32)
     big = MimiSession(eng, max_batch=B, max_chunk_frames=F)
-    one = big.decode(codes)
+    one = big.decode(codes.cuda())
     big.close()
     small = MimiSession(eng, max_batch=B, max_chunk_frames=70)
-    four = small.decode(codes)  # four calls of 70 frames
+    four = small.decode(codes.cuda())  # four calls of 70 frames
     small.close()
     assert one.shape == (B, F * 1920) and bool(torch.isfinite(one).all())
     assert float((one - four).abs().max()) < 1e-5
+    orc = MimiDecodeOracle(st, window=0)
+    for b in (0, B // 2, B - 1):
+        ref = orc.decode(codes[b:b + 1].permute(0, 2, 1).long())[0, 0].numpy()
+        err = _rms(one[b].cpu().numpy() - ref)
+        print(f"slot {b}: rms err vs the oracle {err:.3e} (signal rms {_rms(ref):.3f})")
+        assert err <= RMS_TOL
+    eng.close()
+
+
+def test_decode_at_the_benchmark_shape_matches_oracle():
+    """bench.py's own codec shape in the suite: 32 slots, a chunk of 32 frames then one of 1 (M = 2048 rows in the decoder
+    transformer: the chunk-size conv_xs Linears with the LayerNorm prologue, split-K fc2 + its reduce pass, the XCD-ordered
+    prefill attention over 32 slots, the fused last SEANet stage) against the CPU oracle.  Reference: codec/mimi.py:73-104."""
+    from oracle.mimi_oracle import MimiDecodeOracle
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+    from smoltts_amd.engine import MimiEngine, MimiSession
+
+    st = synthetic_mimi_state(seed=0)
+    B, F = 32, 33
+    eng = MimiEngine(st, 8, window=0, max_positions=2 * F + 16)
+    codes = torch.randint(0, 2048, (B, F, 8), generator=torch.Generator().manual_seed(11), dtype=torch.int32)
+    sess = MimiSession(eng, max_batch=B, max_chunk_frames=32)
+    pcm = sess.decode(codes.cuda()).cpu().numpy()  # chunk 32, then chunk 1
+    sess.close()
+    ref = MimiDecodeOracle(st, window=0).decode(codes.permute(0, 2, 1).long())[:, 0].numpy()
+    err = _rms(pcm - ref)
+    worst = max(_rms(pcm[b] - ref[b]) for b in range(B))
+    print(f"32 slots x 33 frames (chunk 32 + 1): rms err {err:.3e}, worst slot {worst:.3e}, signal rms {_rms(ref):.3f}")
+    assert pcm.shape == ref.shape and err <= RMS_TOL and worst <= RMS_TOL
+    eng.close()
+
+
+def test_hf_vectors_at_chunk_size(golden_dir):
+    """The third-party vectors on the chunk-size kernels: tests/golden/mimi_hf_long.npz (30 frames, PCM from
+    transformers.MimiModel.decode) replicated into 36 slots and decoded as ONE chunk of 30 frames -- 36 x 60 = 2160 rows
+    >= 2048 in the decoder transformer, i.e. the conv_xs / LayerNorm-prologue / split-K fc2 / XCD-ordered attention paths
+    the benchmark runs on -- every slot against the stored PCM."""
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+    from smoltts_amd.engine import MimiEngine, MimiSession
+
+    g = np.load(golden_dir / "mimi_hf_long.npz")
+    codes = torch.from_numpy(g["codes"].astype(np.int32))  # (B0, 8, F)
+    want = g["pcm"].reshape(g["pcm"].shape[0], -1)
+    B0, Q, F = codes.shape
+    assert F == 30
+    reps = -(-36 // B0)
+    dev = codes.permute(0, 2, 1).contiguous().repeat(reps, 1, 1)[:36].contiguous().cuda()  # [36, F, 8]: slot s holds utterance s % B0
+    mst = synthetic_mimi_state(seed=int(g["seed"]))
+    eng = MimiEngine(mst, num_codebooks=Q, window=int(g["window"]) if "window" in g.files else 250, max_positions=2 * F + 16)
+    sess = MimiSession(eng, max_batch=36, max_chunk_frames=F)
+    pcm = sess.decode(dev).cpu().numpy()
+    sess.close()
+    worst = 0.0
+    for s_ in range(36):
+        worst = max(worst, _rms(pcm[s_] - want[s_ % B0]))
+    print(f"mimi_hf_long.npz in 36 slots, one chunk of {F} frames (M = {36 * 2 * F}): worst slot rms err {worst:.2e} "
+          f"(signal rms {_rms(want):.2e})")
+    assert pcm.shape == (36, F * 1920) and worst <= RMS_TOL
     eng.close()
 
 
