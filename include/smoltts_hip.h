@@ -122,6 +122,19 @@ int smoltts_engine_create(const SmolttsLMConfig* cfg, const SmolttsLMWeights* of
                           const void* arena_dev, size_t arena_bytes, SmolttsEngine** out);
 void smoltts_engine_destroy(SmolttsEngine* e);
 
+/* Derived table of an engine (optional, caller-owned memory like everything else): row e of the depth transformer's
+ * embedding table (fast_embeddings, lm/generate.py:134-140) always enters depth layer 0 as RMSNorm(E[e]) -> wqkv, so its
+ * q | k | v (before RoPE) can be looked up instead of computed: [rows][(fast heads + 2 fast kv heads) * 64] fp32 (150m: 73 MB).
+ * With the table in place a frame has 7 launches fewer: the kernel that picks a depth code also gathers the next step's
+ * layer-0 q / k / v (RoPE for its position applied on the way) and that step starts with its attention.  The values are the
+ * decode path's own (same GEMM kernel, same accumulation order).
+ *   smoltts_engine_fast_qkv_bytes   slab size (table + build scratch); 0 if the model has no depth step with a successor
+ *   smoltts_engine_build_fast_qkv   fills the table (synchronises `stream`); the slab must outlive the engine's sessions.
+ * Sessions use the table from their next captured frame on; smoltts_session_set_option(s, SMOLTTS_OPT_QKV_TABLE, 0) keeps one on
+ * the GEMM path. */
+size_t smoltts_engine_fast_qkv_bytes(const SmolttsEngine* e);
+int smoltts_engine_build_fast_qkv(SmolttsEngine* e, void* slab_dev, size_t slab_bytes, void* stream);
+
 /* Session = B utterance slots with KV caches, all inside one caller-allocated device slab.
  * max_rows bounds the prompt rows one smoltts_lm_prefill call may carry; max_frames bounds the
  * frames a slot may emit (output ring). */
@@ -189,6 +202,13 @@ int smoltts_lm_decode(SmolttsSession* s, int32_t n_frames, void* stream);
  * the decode calls (min(n_frames, 8) of the largest call so far -- the default).  Called after a prefill with n > 0 it also
  * captures the graphs now (on `stream`), so that the first decode call of a request does not pay the capture. */
 int smoltts_session_set_frames_per_graph(SmolttsSession* s, int32_t n, void* stream);
+/* Launch-structure options of a session (A/B runs, tests): the ids produced are the same either way; the captured graphs are dropped.
+ *   SMOLTTS_OPT_QKV_TABLE     depth layer-0 q | k | v out of the engine's fast_qkv table where it has been built (default 1)
+ *   SMOLTTS_OPT_COMMIT_PICKS  the frame's slow token and last depth code picked inside the commit kernel instead of in
+ *                             launches of their own (default 1) */
+#define SMOLTTS_OPT_QKV_TABLE 1
+#define SMOLTTS_OPT_COMMIT_PICKS 2
+int smoltts_session_set_option(SmolttsSession* s, int32_t option, int32_t value);
 
 /* Sampling mode (reference GenerationSettings, lm/generate.py:12-16): temp / fast_temp <= 0 select
  * greedy argmax for the slow / depth tokens (the default), otherwise exact categorical sampling from

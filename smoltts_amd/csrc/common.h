@@ -110,10 +110,13 @@ int launch_embed(const int32_t* cols, int n_rows, int n_code_rows, const void* t
                  hipStream_t stream);
 // argmax over each row; writes ids[r*ids_stride]; optionally (emb != nullptr) gathers
 // emb[(id + emb_row_offset)] (bf16 row-major, `dim` wide) into xnext[r].
+struct QkvGather;  // argmax_dev.h
 int launch_argmax(const float* logits, int n_rows, int n_cols, int64_t ld, int32_t* ids,
                   int ids_stride, float* margin, const int32_t* margin_mask, const void* emb,
                   int emb_row_offset, int dim, float* xnext, const EmitArgs* emit, const SampleArgs* sample,
-                  hipStream_t stream);
+                  hipStream_t stream, const QkvGather* qkv = nullptr);
+// rows [row0, row0 + n_rows) of a bf16 embedding table -> X3 operand (x gamma) + sums of squares
+int launch_emb_rows_pack(const void* emb, int64_t row0, int n_rows, int dim, const EmitArgs& emit, hipStream_t stream);
 int launch_layernorm(const float* x, const float* w, const float* b, int n_rows, int dim, float eps,
                      float* out, hipStream_t stream);
 int launch_gather_rows(const float* src, const int32_t* idx, int n, int dim, float* dst,

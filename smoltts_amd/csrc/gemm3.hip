@@ -26,6 +26,9 @@
 #ifndef SMOLTTS_DBG_PIECES
 #define SMOLTTS_DBG_PIECES 3
 #endif
+#ifndef SMOLTTS_DBG_PIECES_RESID  // timing-only variants (tools/ab_pieces.sh): activation pieces read by the residual GEMMs (wo, w2) alone
+#define SMOLTTS_DBG_PIECES_RESID SMOLTTS_DBG_PIECES
+#endif
 
 namespace smoltts {
 
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
   constexpr bool kResid = EPI == SMOLTTS_EPI_RESID;
   constexpr bool kEmits = EPI == SMOLTTS_EPI_RESID || EPI == SMOLTTS_EPI_STORE;
   constexpr bool kRope = EPI == SMOLTTS_EPI_QKV_ROPE;
+  constexpr int kPieces = kResid ? SMOLTTS_DBG_PIECES_RESID : SMOLTTS_DBG_PIECES;  // 3 in the product
   STAMP3(0);
 
   const bool fin = wave < MT;  // waves that will finish the tiles
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int pc = 0; pc < SMOLTTS_DBG_PIECES; ++pc)
+        for (int pc = 0; pc < kPieces; ++pc)
           xf[u][mt][pc] = (cv && xv[mt]) ? *reinterpret_cast<const uint4*>(xb[mt] + (size_t)c * 3072 + pc * 1024)
                                          : make_uint4(0, 0, 0, 0);
       }
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-          for (int pc = 0; pc < SMOLTTS_DBG_PIECES; ++pc)
+          for (int pc = 0; pc < kPieces; ++pc)
             acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8_t, xf[u][mt][pc]), acc[t][mt], 0, 0, 0);
         }
       }

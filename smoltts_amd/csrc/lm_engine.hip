@@ -18,6 +18,7 @@
 
 #include <new>
 
+#include "argmax_dev.h"
 #include "embed_dev.h"
 
 using namespace smoltts;
@@ -27,6 +28,9 @@ struct SmolttsEngine {
   SmolttsLMWeights w;
   const char* arena;
   size_t arena_bytes;
+  // derived table (smoltts_engine_build_fast_qkv; caller-owned memory): q | k | v of depth layer 0 for every row of the fast
+  // embedding table, before RoPE -- [fast_emb_rows][(fast heads + 2 fast kv heads) * 64] fp32; nullptr = not built
+  const float* fast_qkv;
 };
 
 constexpr int STAGE_RING = 8;
@@ -43,7 +47,8 @@ struct SmolttsSession {
   float* qt;                 // [B][max(Hq, fast Hq)*64]
   char *x3n, *x3n2, *x3a, *x3h;  // X3 operands: normed stream (2 consumers), attention out, SwiGLU out
   float* ssq;                // [rows][dim/16] partial sums of squares of the stream
-  float* logits;             // [B][max(vocab, codebook)]
+  float* logits;             // [B][max(vocab, codebook)]: the depth heads' rows
+  float* logits_slow;        // [B][vocab]: the slow head's rows (picked by the commit kernel at the end of the frame)
   // caches
   char *kc, *vc;             // [n_layer][B][KV][max_seq][64] in fp32 or bf16 (kv_format)
   int kv_format;
@@ -80,6 +85,8 @@ struct SmolttsSession {
   int flight_cur, flight_count, flight_group;
   // measurement aid of THIS session (smoltts_session_measure_duplicate): launches of one kernel class are issued twice
   int dup_code, dup_n;
+  bool use_qkv_table;          // depth layer-0 q | k | v from the engine's table where it exists (SMOLTTS_OPT_QKV_TABLE)
+  bool commit_picks;           // slow token and last depth code picked inside the commit kernel (SMOLTTS_OPT_COMMIT_PICKS)
 };
 
 namespace {
@@ -117,6 +124,7 @@ void carve(SmolttsSession* s, char* base, size_t* total) {
   s->x3h = cv.take<char>(R16 * imx * 6);
   s->ssq = cv.take<float>(R16 * (dmax / 16));
   s->logits = cv.take<float>(B * (size_t)imax(c.vocab_size, c.codebook_size));
+  s->logits_slow = cv.take<float>(B * (size_t)c.vocab_size);
   const size_t kv = (size_t)c.n_layer * B * c.n_kv_head * s->max_seq * 64 * (s->kv_format == SMOLTTS_KV_BF16 ? 2 : 4);
   s->kc = cv.take<char>(kv);
   s->vc = cv.take<char>(kv);
@@ -206,33 +214,48 @@ __global__ void slot_park_kernel(int B, int n_slots, const int* slots, const int
 // Invariant between API calls: (xt, x3n, ssq) hold the embedded current columns of all slots and mask == !done.
 struct CommitArgs {
   int B, H, max_frames, max_seq, im_end, stop_on_eos, advance_pos, do_commit;
-  const int* new_col;
+  int* new_col;
   int *mask, *cur_col, *codes, *pos, *frames, *done;
+  // the two picks nothing else in the frame waits for happen here instead of in launches of their own: the slow token
+  // (lm/generate.py:88-99: only the commit needs it) and the last depth code (no further step consumes it); null = already in new_col
+  const float* slow_logits; int slow_cols; SampleArgs slow_sa;
+  const float* last_logits; int last_cols; SampleArgs last_sa;
+  float* margin;
 };
 
 __global__ __launch_bounds__(256) void commit_embed_kernel(CommitArgs a, EmbedTables t, float* xt, EmitDev emit) {
   __shared__ int s_col[64];
   __shared__ float sh4[4];
+  __shared__ ArgmaxScratch s_pick[2];
   const int b = blockIdx.x, tid = threadIdx.x, H = a.H;  // H <= 64: the whole commit happens inside wave 0, in program order
+  int id_slow = 0, id_last = 0;
+  if (a.slow_logits) id_slow = argmax_row(a.slow_logits + (long)b * a.slow_cols, a.slow_cols, (a.slow_cols & 3) == 0, b, a.margin, a.mask, a.slow_sa, s_pick[0]);
+  if (a.last_logits) id_last = argmax_row(a.last_logits + (long)b * a.last_cols, a.last_cols, (a.last_cols & 3) == 0, b, a.margin, a.mask, a.last_sa, s_pick[1]);
   int f = 0;
   bool live = false;
   if (tid < 64) { f = a.frames[b]; live = a.do_commit && a.mask[b]; }
   const bool publish = live && f < a.max_frames;
+  int slow_now = 0;
   if (tid < H) {
-    const int v = publish ? a.new_col[b * H + tid] : a.cur_col[b * H + tid];
+    int nv = a.new_col[b * H + tid];
+    if (a.slow_logits && tid == 0) nv = id_slow;
+    if (a.last_logits && tid == H - 1) nv = id_last;
+    if ((a.slow_logits && tid == 0) || (a.last_logits && tid == H - 1)) a.new_col[b * H + tid] = nv;  // (the host-visible column stays whole)
+    const int v = publish ? nv : a.cur_col[b * H + tid];
     s_col[tid] = v;
     if (publish) {
       a.cur_col[b * H + tid] = v;
       a.codes[((long)b * a.max_frames + f) * H + tid] = v;
     }
   }
+  slow_now = a.slow_logits ? id_slow : a.new_col[b * H];  // (tid 0 reads what it may just have written itself)
   if (tid == 0) {
     int d = a.done[b];
     if (live) {
       int p = a.pos[b];
       if (a.advance_pos) a.pos[b] = ++p;
       if (publish) a.frames[b] = f + 1;
-      if ((a.stop_on_eos && a.new_col[b * H] == a.im_end) || f + 1 >= a.max_frames || p >= a.max_seq) a.done[b] = d = 1;
+      if ((a.stop_on_eos && slow_now == a.im_end) || f + 1 >= a.max_frames || p >= a.max_seq) a.done[b] = d = 1;
     }
     a.mask[b] = !d;
   }
@@ -266,14 +289,16 @@ int launch_gemm3_m(const SmolttsSession* s, const SmolttsGemm3Args& a, hipStream
 int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, int n_head, int n_kv, int inter, float* x,
               float* q, int M, const int* row_pos, const int* row_slot, const float* rope, void* kc, void* vc,
               int cache_len, const char* in_x3, const EmitArgs& next, hipStream_t st, bool first_pos = false,
-              int kv_format = SMOLTTS_KV_F32, int iota_pos = -1) {
+              int kv_format = SMOLTTS_KV_F32, int iota_pos = -1, bool qkv_done = false) {
+  // qkv_done: q and the cache rows of this block are in place already (gathered from the engine's fast_qkv table by the
+  // kernel that picked the row's code): no wqkv launch
   // iota_pos >= 0: row r is slot r at that position (the depth steps): the attention kernel needs no row_pos / row_slot loads
   // first_pos: every row is at position 0 (depth step 0), so attention over its single key is the row's own V: the QKV
   // epilogue publishes V as wo's operand and the attention launch is skipped.
   const SmolttsEngine* e = s->e;
   const char* A = e->arena;
   const float eps = e->cfg.norm_eps;
-  {  // RMSNorm scale + QKV + RoPE + cache write
+  if (!qkv_done) {  // RMSNorm scale + QKV + RoPE + cache write
     SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.wqkv, in_x3, M, (n_head + 2 * n_kv) * 64, dim, SMOLTTS_EPI_QKV_ROPE);
     a.ssq_in_dev = s->ssq; a.eps = eps; a.out_dev = q; a.ldo = n_head * 64;
     a.rope_dev = rope; a.row_pos_dev = row_pos; a.row_slot_dev = row_slot;
@@ -336,13 +361,24 @@ EmbedTables embed_tables(const SmolttsEngine* e) {
                      c.vocab_size, c.codebook_size * c.num_codebooks, c.n_fast};
 }
 
-// commit (optional) + next-frame mask + embedding of every slot's current column (see commit_embed_kernel)
-int launch_commit_embed(SmolttsSession* s, int do_commit, int advance_pos, hipStream_t st) {
+// commit (optional) + next-frame mask + embedding of every slot's current column (see commit_embed_kernel); `picks`: the
+// frame's slow token and last depth code are still logits (run_tail) and are picked here
+int launch_commit_embed(SmolttsSession* s, int do_commit, int advance_pos, hipStream_t st, bool picks = false) {
   const SmolttsEngine* e = s->e;
   const SmolttsLMConfig& c = e->cfg;
   ST_REQUIRE(1 + c.n_fast <= 64 && c.dim % 64 == 0, SMOLTTS_E_INVALID, "commit: grid height > 64 or dim %% 64 != 0");
-  const CommitArgs a{s->B, 1 + c.n_fast, s->max_frames, s->max_seq, c.im_end_id, s->stop_on_eos, advance_pos, do_commit,
-                     s->new_col, s->mask, s->cur_col, s->codes, s->pos, s->frames, s->done};
+  CommitArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = s->B; a.H = 1 + c.n_fast; a.max_frames = s->max_frames; a.max_seq = s->max_seq; a.im_end = c.im_end_id;
+  a.stop_on_eos = s->stop_on_eos; a.advance_pos = advance_pos; a.do_commit = do_commit;
+  a.new_col = s->new_col; a.mask = s->mask; a.cur_col = s->cur_col; a.codes = s->codes; a.pos = s->pos; a.frames = s->frames; a.done = s->done;
+  a.margin = s->margin;
+  if (picks) {
+    a.slow_logits = s->logits_slow; a.slow_cols = c.vocab_size;
+    a.slow_sa = SampleArgs{s->temp, s->min_p, s->seed, 0, 0, s->frames, s->salt, s->margin_at};
+    a.last_logits = s->logits; a.last_cols = c.codebook_size;
+    a.last_sa = SampleArgs{s->fast_temp, s->fast_temp > 0.f ? s->min_p : 0.f, s->seed, c.n_fast, 0, s->frames, s->salt, s->margin_at};
+  }
   const EmitDev em{s->x3n, gamma_at(e, e->w.layers[0].attn_norm), nullptr, nullptr, s->ssq};
   hipLaunchKernelGGL(commit_embed_kernel, dim3(s->B), dim3(256), 0, st, a, embed_tables(e), s->xt, em);
   ST_CHECK_HIP(hipGetLastError());
@@ -356,14 +392,17 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
   const SmolttsLMConfig& c = e->cfg;
   const char* A = e->arena;
   const int B = s->B, H = 1 + c.n_fast;
-  {  // logits = RMSNorm(x) . E^T   (lm/rq_transformer.py:184-189)
+  {  // logits = RMSNorm(x) . E^T   (lm/rq_transformer.py:184-189); the token is picked by the commit kernel: nothing before it needs it
     SmolttsGemm3Args a = base3(c.weight_format, A + e->w.head, s->x3n, B, c.vocab_size, c.dim, SMOLTTS_EPI_STORE);
-    a.ssq_in_dev = s->ssq; a.eps = c.norm_eps; a.out_dev = s->logits; a.ldo = c.vocab_size;
+    a.ssq_in_dev = s->ssq; a.eps = c.norm_eps; a.out_dev = s->logits_slow; a.ldo = c.vocab_size;
     ST_TRY(launch_gemm3_m(s, a, st));
   }
-  const SampleArgs slow_sa{s->temp, s->min_p, s->seed, 0, 0, s->frames, s->salt, s->margin_at};
-  ST_TRY(launch_argmax(s->logits, B, c.vocab_size, c.vocab_size, s->new_col, H, s->margin, s->mask, nullptr, 0, 0, nullptr,
-                       nullptr, &slow_sa, st));
+  const bool picks = s->commit_picks;
+  if (!picks) {  // (A/B: the pick as a launch of its own)
+    const SampleArgs slow_sa{s->temp, s->min_p, s->seed, 0, 0, s->frames, s->salt, s->margin_at};
+    ST_TRY(launch_argmax(s->logits_slow, B, c.vocab_size, c.vocab_size, s->new_col, H, s->margin, s->mask, nullptr, 0, 0, nullptr,
+                         nullptr, &slow_sa, st));
+  }
   float* xf = s->xt;  // fast input = pre-norm slow hidden (lm/rq_transformer.py:191)
   const char* first_x3 = s->x3n2;
   const EmitArgs to_fast0{s->x3n, gamma_at(e, e->w.fast_layers[0].attn_norm), nullptr, nullptr, s->ssq};
@@ -376,6 +415,7 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
     first_x3 = s->x3n;
   }
   const size_t fl_stride = (size_t)B * c.fast_n_kv_head * c.n_fast * 64;
+  const bool table = e->fast_qkv != nullptr && s->use_qkv_table;
   for (int i = 0; i < c.n_fast; ++i) {
     for (int l = 0; l < c.n_fast_layer; ++l) {
       const EmitArgs next{s->x3n,
@@ -384,7 +424,7 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
       ST_TRY(run_block(s, e->w.fast_layers[l], c.fast_dim, c.fast_n_head, c.fast_n_kv_head, c.fast_inter, xf, s->qt, B,
                        s->fastpos + (size_t)i * B, s->iota, (const float*)(A + e->w.fast_rope), s->fkc + l * fl_stride,
                        s->fvc + l * fl_stride, c.n_fast, (i == 0 && l == 0) ? first_x3 : s->x3n, next, st, /*first_pos=*/i == 0,
-                       SMOLTTS_KV_F32, /*iota_pos=*/i));
+                       SMOLTTS_KV_F32, /*iota_pos=*/i, /*qkv_done=*/table && i > 0 && l == 0));
     }
     {  // fast_norm + depthwise head slice i  (lm/rq_transformer.py:209-217)
       const size_t wrow = (size_t)i * e->w.fast_head_step_stride;  // rows; a row tile is 16 rows
@@ -393,16 +433,27 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
       a.ssq_in_dev = s->ssq; a.eps = c.norm_eps; a.out_dev = s->logits; a.ldo = c.codebook_size;
       ST_TRY(launch_gemm3_m(s, a, st));
     }
-    const bool more = i + 1 < c.n_fast;
+    const SampleArgs fast_sa{s->fast_temp, s->fast_temp > 0.f ? s->min_p : 0.f, s->seed, 1 + i, 0, s->frames, s->salt, s->margin_at};
+    if (i + 1 == c.n_fast) {  // the last code has no consumer inside the frame: picked by the commit kernel
+      if (!picks)
+        ST_TRY(launch_argmax(s->logits, B, c.codebook_size, c.codebook_size, s->new_col + 1 + i, H, s->margin, s->mask, nullptr, 0, 0,
+                             nullptr, nullptr, &fast_sa, st));
+      break;
+    }
     const int off = c.depthwise_wte ? (c.duplicate_code_0 ? i : i + 1) * c.codebook_size : 0;  // generate.py:136-140
     float* xnext = c.has_fast_project_in ? s->xf : s->xt;
-    const SampleArgs fast_sa{s->fast_temp, s->fast_temp > 0.f ? s->min_p : 0.f, s->seed, 1 + i, 0, s->frames, s->salt, s->margin_at};
+    // the next step's layer-0 q | k | v come out of the engine's table (position i + 1) where it has been built: the row then
+    // needs no X3 operand of its own, only the fp32 residual
+    QkvGather qg;
+    memset(&qg, 0, sizeof(qg));
+    if (table)
+      qg = QkvGather{e->fast_qkv, (const float*)(A + e->w.fast_rope), s->qt, s->fkc, s->fvc, c.fast_n_head, c.fast_n_kv_head, c.n_fast, i + 1};
     ST_TRY(launch_argmax(s->logits, B, c.codebook_size, c.codebook_size, s->new_col + 1 + i, H, s->margin, s->mask,
-                         more ? (const void*)(A + e->w.fast_emb) : nullptr, off, c.fast_dim, more ? xnext : nullptr,
-                         more ? &to_fast0 : nullptr, &fast_sa, st));
+                         (const void*)(A + e->w.fast_emb), off, c.fast_dim, xnext, table ? nullptr : &to_fast0, &fast_sa, st,
+                         table ? &qg : nullptr));
     xf = xnext;
   }
-  return launch_commit_embed(s, /*do_commit=*/1, advance_pos, st);
+  return launch_commit_embed(s, /*do_commit=*/1, advance_pos, st, picks);
 }
 
 // Slow transformer over M rows of x (already embedded and published for layer 0).
@@ -568,11 +619,65 @@ int smoltts_engine_create(const SmolttsLMConfig* cfg, const SmolttsLMWeights* of
   SmolttsEngine* e = new (std::nothrow) SmolttsEngine;
   ST_REQUIRE(e, SMOLTTS_E_INVALID, "engine_create: out of host memory");
   e->cfg = c; e->w = *offsets; e->arena = (const char*)arena_dev; e->arena_bytes = arena_bytes;
+  e->fast_qkv = nullptr;
   *out = e;
   return SMOLTTS_OK;
 }
 
 void smoltts_engine_destroy(SmolttsEngine* e) { delete e; }
+
+// ---- derived table: depth layer-0 q | k | v of every fast-embedding row (see QkvGather in argmax_dev.h)
+// Rows a depth step can be fed with: code + offset of the steps that have a successor (lm/generate.py:134-140).
+static long fast_emb_rows_used(const SmolttsLMConfig& c) {
+  if (c.n_fast < 2) return 0;
+  return c.depthwise_wte ? (long)(c.duplicate_code_0 ? c.n_fast - 1 : c.n_fast) * c.codebook_size : (long)c.codebook_size;
+}
+constexpr int QKV_BUILD_ROWS = 128;  // rows per GEMM launch of the build: the decode kernels' own variant (M <= 128)
+
+size_t smoltts_engine_fast_qkv_bytes(const SmolttsEngine* e) {
+  if (!e) return 0;
+  const SmolttsLMConfig& c = e->cfg;
+  const long rows = fast_emb_rows_used(c);
+  if (rows <= 0) return 0;
+  const size_t nqkv = (size_t)(c.fast_n_head + 2 * c.fast_n_kv_head) * 64;
+  const size_t table = align_up((size_t)rows * nqkv * sizeof(float));
+  const size_t x3 = align_up((size_t)QKV_BUILD_ROWS * c.fast_dim * 6), ssq = align_up((size_t)QKV_BUILD_ROWS * (c.fast_dim / 16) * sizeof(float));
+  return table + x3 + ssq;
+}
+
+int smoltts_engine_build_fast_qkv(SmolttsEngine* e, void* slab_dev, size_t slab_bytes, void* stream) {
+  ST_REQUIRE(e && slab_dev, SMOLTTS_E_INVALID, "engine_build_fast_qkv: null argument");
+  const SmolttsLMConfig& c = e->cfg;
+  const size_t need = smoltts_engine_fast_qkv_bytes(e);
+  ST_REQUIRE(need > 0, SMOLTTS_E_INVALID, "engine_build_fast_qkv: this model has no depth step with a successor");
+  ST_REQUIRE(slab_bytes >= need && ((uintptr_t)slab_dev & 255) == 0, SMOLTTS_E_CAPACITY,
+             "engine_build_fast_qkv: slab has %zu bytes (256-byte aligned), %zu needed", slab_bytes, need);
+  const long rows = fast_emb_rows_used(c);
+  ST_REQUIRE(e->w.fast_emb % 16 == 0 && e->w.fast_emb + (size_t)rows * c.fast_dim * 2 <= e->arena_bytes, SMOLTTS_E_INVALID,
+             "engine_build_fast_qkv: the fast embedding table (%ld rows) lies outside the arena", rows);
+  hipStream_t st = (hipStream_t)stream;
+  const char* A = e->arena;
+  const int nqkv = (c.fast_n_head + 2 * c.fast_n_kv_head) * 64;
+  Carver cv{(char*)slab_dev, 0};
+  float* table = cv.take<float>((size_t)rows * nqkv);
+  char* x3 = cv.take<char>((size_t)QKV_BUILD_ROWS * c.fast_dim * 6);
+  float* ssq = cv.take<float>((size_t)QKV_BUILD_ROWS * (c.fast_dim / 16));
+  e->fast_qkv = nullptr;
+  const SmolttsBlockWeights& bw = e->w.fast_layers[0];
+  const EmitArgs em{x3, gamma_at(e, bw.attn_norm), nullptr, nullptr, ssq};
+  for (long r0 = 0; r0 < rows; r0 += QKV_BUILD_ROWS) {
+    const int n = (int)(rows - r0 < QKV_BUILD_ROWS ? rows - r0 : QKV_BUILD_ROWS);
+    // the row exactly as the picking kernel would publish it (X3 of E[row] * attention_norm + its sum of squares) ...
+    ST_TRY(launch_emb_rows_pack(A + e->w.fast_emb, r0, n, c.fast_dim, em, st));
+    // ... through the decode path's own wqkv GEMM (same accumulation order), the RMSNorm scale applied, RoPE left to the gather
+    SmolttsGemm3Args a = base3(c.weight_format, A + bw.wqkv, x3, n, nqkv, c.fast_dim, SMOLTTS_EPI_STORE);
+    a.ssq_in_dev = ssq; a.eps = c.norm_eps; a.out_dev = table + (size_t)r0 * nqkv; a.ldo = nqkv;
+    ST_TRY(launch_gemm3(a, st));
+  }
+  ST_CHECK_HIP(hipStreamSynchronize(st));  // the scratch part of the slab is dead from here; the table part must outlive the engine's sessions
+  e->fast_qkv = table;
+  return SMOLTTS_OK;
+}
 
 size_t smoltts_session_slab_bytes(const SmolttsEngine* e, int32_t max_batch, int32_t max_seq, int32_t max_rows,
                                   int32_t max_frames) {
@@ -614,6 +719,8 @@ int smoltts_session_create_kv(SmolttsEngine* e, void* slab_dev, size_t slab_byte
   memset(s, 0, sizeof(*s));
   s->e = e; s->B = max_batch; s->max_seq = max_seq; s->max_rows = max_rows; s->max_frames = max_frames;
   s->dup_code = -1;
+  s->use_qkv_table = true;
+  s->commit_picks = true;
   s->kv_format = kv_format;
   size_t total = 0;
   carve(s, (char*)slab_dev, &total);
@@ -831,6 +938,21 @@ int smoltts_session_measure_duplicate(SmolttsSession* s, int32_t code, int32_t n
   ST_REQUIRE(s, SMOLTTS_E_INVALID, "session_measure_duplicate: null session");
   ST_REQUIRE(code != SMOLTTS_EPI_RESID, SMOLTTS_E_INVALID, "session_measure_duplicate: EPI_RESID launches are not idempotent");
   s->dup_code = code; s->dup_n = n_filter;
+  drop_graphs(s);
+  return SMOLTTS_OK;
+}
+
+// Launch-structure options of a session (both default on; switching one drops the captured graphs): the ids are the same
+// either way -- the switches exist for A/B runs and tests.
+int smoltts_session_set_option(SmolttsSession* s, int32_t option, int32_t value) {
+  ST_REQUIRE(s, SMOLTTS_E_INVALID, "session_set_option: null session");
+  switch (option) {
+    case SMOLTTS_OPT_QKV_TABLE: s->use_qkv_table = value != 0; break;
+    case SMOLTTS_OPT_COMMIT_PICKS: s->commit_picks = value != 0; break;
+    default:
+      set_error("session_set_option: unknown option %d", option);
+      return SMOLTTS_E_INVALID;
+  }
   drop_graphs(s);
   return SMOLTTS_OK;
 }

@@ -104,7 +104,7 @@ _EXPORTS = [
     "smoltts_mimi_slab_bytes", "smoltts_mimi_session_create", "smoltts_mimi_session_destroy", "smoltts_mimi_reset",
     "smoltts_mimi_decode_chunk", "smoltts_k_gemm", "smoltts_k_attention", "smoltts_k_embed", "smoltts_k_argmax",
     "smoltts_k_layernorm", "smoltts_k_gemm3", "smoltts_k_x3_pack",
-    "smoltts_session_measure_duplicate", "smoltts_session_margin_at", "smoltts_session_drop_graph", "smoltts_session_set_frames_per_graph",
+    "smoltts_session_measure_duplicate", "smoltts_session_margin_at", "smoltts_session_drop_graph", "smoltts_session_set_frames_per_graph", "smoltts_engine_fast_qkv_bytes", "smoltts_engine_build_fast_qkv", "smoltts_session_set_option",
     "smoltts_session_slab_bytes_kv", "smoltts_session_create_kv", "smoltts_k_attention_kv", "smoltts_session_set_sampling", "smoltts_k_sample",
     "smoltts_lm_prefill_chunk", "smoltts_lm_prefill_deferred", "smoltts_mimi_reset_slots", "smoltts_mimi_encoder_create", "smoltts_mimi_encoder_destroy", "smoltts_mimi_encode_frames",
     "smoltts_mimi_encode_workspace_bytes", "smoltts_mimi_encode",
@@ -168,6 +168,10 @@ def load_library(path: Optional[Path] = None):
     lib.smoltts_session_margin_at.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     lib.smoltts_session_drop_graph.argtypes = [C.c_void_p]
     lib.smoltts_session_set_frames_per_graph.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.smoltts_engine_fast_qkv_bytes.argtypes = [C.c_void_p]
+    lib.smoltts_engine_fast_qkv_bytes.restype = C.c_size_t
+    lib.smoltts_engine_build_fast_qkv.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.smoltts_session_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.smoltts_mimi_reset_slots.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.smoltts_lm_prefill_deferred.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                                 C.c_int32, C.c_void_p]
@@ -286,14 +290,19 @@ def _fill_block(dst: BlockWeights, src: Dict[str, int]) -> None:
         setattr(dst, k, v)
 
 
+OPT_QKV_TABLE, OPT_COMMIT_PICKS = 1, 2  # include/smoltts_hip.h SMOLTTS_OPT_*
+
+
 class LMEngine:
     """Immutable model on one GPU: packed weight arena + ``SmolttsEngine`` handle."""
 
     def __init__(self, cfg: RQTransformerModelArgs, state: Dict[str, torch.Tensor], token_config: TokenConfig,
                  numerics: Optional[NumericsMode] = None, arena: Optional[torch.Tensor] = None, offsets=None,
-                 weight_format: str = "bf16"):
+                 weight_format: str = "bf16", fast_qkv_table: Optional[bool] = None):
         """``weight_format="fp8"``: the Linears are stored as e4m3 with per-row scales (half the weight bytes);
-        the model computed is exactly ``packing.fp8_reference_state`` of the checkpoint."""
+        the model computed is exactly ``packing.fp8_reference_state`` of the checkpoint.
+        ``fast_qkv_table`` (default on; ``SMOLTTS_QKV_TABLE=0`` switches the default off): build the engine's derived table of
+        depth layer-0 q | k | v per fast-embedding row (``smoltts_engine_build_fast_qkv``: 7 launches fewer per frame)."""
         cfg.validate_for_engine()
         self.lib = load_library()
         self.device = _require_gpu()
@@ -319,6 +328,14 @@ class LMEngine:
         check(self.lib.smoltts_engine_create(C.byref(self.c_cfg), C.byref(w), dptr(self.arena), self.arena.numel(), C.byref(h)),
               "smoltts_engine_create")
         self.handle = h
+        if fast_qkv_table is None:
+            fast_qkv_table = os.environ.get("SMOLTTS_QKV_TABLE", "1") != "0"
+        self.fast_qkv = None
+        need = self.lib.smoltts_engine_fast_qkv_bytes(self.handle) if fast_qkv_table else 0
+        if need:
+            self.fast_qkv = _alloc_slab(need, self.device)
+            check(self.lib.smoltts_engine_build_fast_qkv(self.handle, dptr(self.fast_qkv), need, current_stream_ptr()),
+                  "smoltts_engine_build_fast_qkv")
 
     @property
     def grid_height(self) -> int:
@@ -380,6 +397,8 @@ class LMSession:
         check(self.lib.smoltts_session_margin_at(h, C.byref(mp)), "smoltts_session_margin_at")
         self.margin_at = view(mp, self.B * 4, torch.int32, (self.B,))  # frame * 64 + step of each slot's smallest gap
         self._keep = None
+        if os.environ.get("SMOLTTS_COMMIT_PICKS") == "0":  # A/B switch of tools/ (the ids are the same either way)
+            self.use_commit_picks(False)
 
     def prefill(self, prompts: Sequence[np.ndarray], slots: Optional[Sequence[int]] = None, stop_on_eos: bool = True,
                 pos0: Optional[Sequence[int]] = None, final: bool = True, defer_frame0: bool = False) -> None:
@@ -456,6 +475,14 @@ class LMSession:
 
     def decode(self, n_frames: int) -> None:
         check(self.lib.smoltts_lm_decode(self.handle, int(n_frames), current_stream_ptr()), "smoltts_lm_decode")
+
+    def use_qkv_table(self, on: bool) -> None:
+        """Depth layer-0 q | k | v from the engine's table (default where it exists) or through the wqkv GEMM (A/B, tests)."""
+        check(self.lib.smoltts_session_set_option(self.handle, OPT_QKV_TABLE, 1 if on else 0), "smoltts_session_set_option")
+
+    def use_commit_picks(self, on: bool) -> None:
+        """The frame's slow token and last depth code picked inside the commit kernel (default) or in launches of their own."""
+        check(self.lib.smoltts_session_set_option(self.handle, OPT_COMMIT_PICKS, 1 if on else 0), "smoltts_session_set_option")
 
     def set_frames_per_graph(self, n: int) -> None:
         """Frames per multi-frame graph (1 = single-frame graphs, 0 = follow the decode calls).  After a prefill and with

@@ -9,3 +9,10 @@ for n in 2 1; do
   lib=$(python -m smoltts_amd.build --variant pieces_$n --flags "-DSMOLTTS_DBG_PIECES=$n" | tail -1)
   SMOLTTS_LIB=$lib run
 done
+# the residual GEMMs alone (wo, w2: VERDICT r02 item 1c -- an upper bound on what a smaller activation operand for them can buy:
+# one piece = a third of their X3 bytes AND a third of their MFMAs)
+for n in 2 1; do
+  echo "== pieces of wo / w2 only: $n"
+  lib=$(python -m smoltts_amd.build --variant pieces_resid_$n --flags "-DSMOLTTS_DBG_PIECES_RESID=$n" | tail -1)
+  SMOLTTS_LIB=$lib run
+done
