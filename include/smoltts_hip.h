@@ -205,9 +205,13 @@ int smoltts_session_set_frames_per_graph(SmolttsSession* s, int32_t n, void* str
 /* Launch-structure options of a session (A/B runs, tests): the ids produced are the same either way; the captured graphs are dropped.
  *   SMOLTTS_OPT_QKV_TABLE     depth layer-0 q | k | v out of the engine's fast_qkv table where it has been built (default 1)
  *   SMOLTTS_OPT_COMMIT_PICKS  the frame's slow token and last depth code picked inside the commit kernel instead of in
- *                             launches of their own (default 1) */
+ *                             launches of their own (default 1)
+ *   SMOLTTS_OPT_SPLIT_ATTN    decode attention over the slow cache with the keys of a (row, kv head) pair on two workgroups,
+ *                             merged in part order inside the launch (<= 128 pairs, i.e. B <= 32 at 4 kv heads; default 1).
+ *                             fp32 sums in a different order than the one-workgroup kernel: same ids except at near-ties */
 #define SMOLTTS_OPT_QKV_TABLE 1
 #define SMOLTTS_OPT_COMMIT_PICKS 2
+#define SMOLTTS_OPT_SPLIT_ATTN 3
 int smoltts_session_set_option(SmolttsSession* s, int32_t option, int32_t value);
 
 /* Sampling mode (reference GenerationSettings, lm/generate.py:12-16): temp / fast_temp <= 0 select
@@ -467,6 +471,14 @@ int smoltts_k_attention_kv(const float* q_dev, const void* k_cache_dev, const vo
                            const int32_t* row_pos_dev, const int32_t* row_slot_dev, int32_t n_rows,
                            int32_t n_q_heads, int32_t n_kv_heads, int32_t cache_len, int32_t window,
                            float* out_dev, void* out_x3_dev, int32_t kv_format, void* stream);
+/* The same with the keys of every (row, kv head) pair dealt over two workgroups and merged inside the launch (decode frames
+ * at B <= 32: rows x kv heads <= 128, caches longer than 128 entries; other shapes run the one-workgroup kernels).
+ * split_part_dev: 128 * 2 * (4 * 64 + 8) floats of scratch; split_ticket_dev: 128 int32 zeroed ONCE (tickets count up across
+ * launches: two arrivals per pair and launch). */
+int smoltts_k_attention_split(const float* q_dev, const void* k_cache_dev, const void* v_cache_dev, const int32_t* row_pos_dev,
+                              const int32_t* row_slot_dev, int32_t n_rows, int32_t n_q_heads, int32_t n_kv_heads, int32_t cache_len,
+                              int32_t window, float* out_dev, void* out_x3_dev, int32_t kv_format, float* split_part_dev,
+                              int32_t* split_ticket_dev, void* stream);
 
 /* x[r] = E_text[cols[r][0]] + keep * sum_k E_cb[cols[r][1+k] + k*codebook_size] */
 int smoltts_k_embed(const int32_t* cols_dev, int32_t n_rows, int32_t n_code_rows,

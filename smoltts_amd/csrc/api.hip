@@ -40,6 +40,15 @@ int smoltts_k_attention_kv(const float* q_dev, const void* k_cache_dev, const vo
                           window, out_dev, out_x3_dev, (hipStream_t)stream, kv_format);
 }
 
+int smoltts_k_attention_split(const float* q_dev, const void* k_cache_dev, const void* v_cache_dev, const int32_t* row_pos_dev,
+                              const int32_t* row_slot_dev, int32_t n_rows, int32_t n_q_heads, int32_t n_kv_heads, int32_t cache_len,
+                              int32_t window, float* out_dev, void* out_x3_dev, int32_t kv_format, float* split_part_dev,
+                              int32_t* split_ticket_dev, void* stream) {
+  ST_REQUIRE(split_part_dev && split_ticket_dev, SMOLTTS_E_INVALID, "k_attention_split: null scratch");
+  return launch_attention(q_dev, k_cache_dev, v_cache_dev, row_pos_dev, row_slot_dev, n_rows, n_q_heads, n_kv_heads, cache_len,
+                          window, out_dev, out_x3_dev, (hipStream_t)stream, kv_format, -1, split_part_dev, split_ticket_dev);
+}
+
 int smoltts_k_embed(const int32_t* cols_dev, int32_t n_rows, int32_t n_code_rows, const void* text_emb_dev,
                     const void* cb_emb_dev, int32_t dim, int32_t codebook_size, int32_t cb_first_offset, int32_t mask_mode,
                     int32_t sem_start, int32_t sem_end, float* x_dev, void* stream) {

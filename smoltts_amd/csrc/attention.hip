@@ -29,6 +29,8 @@ struct AttnDev {
   int n_q_heads, n_kv_heads, cache_len, window, score_cap;
   int iota_pos;  // >= 0 (short-cache kernel): every row r is at this position of slot r -- the depth transformer's steps; no
                  // row_pos / row_slot round trip in front of the cache loads
+  float* split_part;   // attn_split_kernel with NS > 1: [pairs][NS][G * 64 + 8] partial (sums | max, denominator) records
+  int* split_ticket;   // [pairs] arrival tickets, counting up across launches (NS arrivals per pair and launch)
 };
 
 // 4 consecutive cache elements starting at element index e: fp32 (16 B) or bf16 (8 B, widened exactly)
@@ -174,6 +176,280 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
       sum.x = fmaf(t.x, sc, sum.x); sum.y = fmaf(t.y, sc, sum.y); sum.z = fmaf(t.z, sc, sum.z); sum.w = fmaf(t.w, sc, sum.w);
       dsum = fmaf(stat[(w * G + g) * 2 + 1], sc, dsum);
     }
+    const float inv = 1.0f / dsum;
+    const int k = (h * G + g) * 64 + d4;
+    // rounded once (no contraction into the X3 split): the fp32 and the X3 outputs are the same numbers
+    const float ox = __fmul_rn(sum.x, inv), oy = __fmul_rn(sum.y, inv), oz = __fmul_rn(sum.z, inv), ow = __fmul_rn(sum.w, inv);
+    if (p.out) *reinterpret_cast<float4*>(p.out + (long)row * HD + k) = make_float4(ox, oy, oz, ow);
+    if (p.out_x3) x3_emit4(p.out_x3, row, k, HD >> 5, ox, oy, oz, ow);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Decode-time attention over a long cache, second form: (a) the keys of one (row, kv head) pair can be dealt over NS
+// workgroups -- with B = 32 slots x 4 kv heads the plain kernel keeps only 128 of the 256 CUs streaming, and a CU cannot keep
+// more than a few tens of KB of HBM reads in flight, so the cache arrives at about half of what the chip can stream; (b) a bf16
+// cache is read with 8 lanes per key and 16-byte loads (8 elements per lane), so that it halves the load instructions as well
+// as the bytes (the plain kernel keeps 16 lanes per key: 8-byte loads, same instruction count as fp32).
+// The NS partial results (unnormalised sums, running maximum, denominator) meet inside the launch: every workgroup stores its
+// record write-through (sc1), drains, and takes a ticket; the one whose ticket completes the pair loads all NS records (sc1)
+// and merges them IN PART ORDER -- deterministic whoever arrives last -- then normalises and writes the row
+// (MI355X_MICROARCH.md "Valid forms", first table row: one lane adds to one counter behind the storing wave's vmcnt(0); the
+// workgroup whose add returned last loads, all loads sc1).  Tickets count up across launches (NS arrivals per pair and launch).
+constexpr int ATT_PS_PAD = 8;  // floats behind the G * 64 sums of a record: (max, denominator) per head
+constexpr int ATT_SPLIT_MIN_KEYS = 512;  // rows with fewer cached keys run on one workgroup
+
+template <int LPK>
+__device__ __forceinline__ float group_sum(float x) {  // sum over the LPK (8 or 16) lanes of a key's lane group, result in every lane
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  if (LPK == 16) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true));  // row_mirror
+  return x;
+}
+
+template <bool KB> struct KVLane { static constexpr int LPK = KB ? 8 : 16, DPL = 64 / LPK; float v[DPL]; };
+
+template <bool KB>
+__device__ __forceinline__ void load_kv_lane(const void* base, long e, bool ok, KVLane<KB>& o) {
+  if constexpr (KB) {  // 8 bf16 elements, widened exactly
+    const uint4 t = ok ? *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(base) + e) : make_uint4(0, 0, 0, 0);
+    o.v[0] = bf16_lo(t.x); o.v[1] = bf16_hi(t.x); o.v[2] = bf16_lo(t.y); o.v[3] = bf16_hi(t.y);
+    o.v[4] = bf16_lo(t.z); o.v[5] = bf16_hi(t.z); o.v[6] = bf16_lo(t.w); o.v[7] = bf16_hi(t.w);
+  } else {
+    const float4 t = ok ? *reinterpret_cast<const float4*>(static_cast<const float*>(base) + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+    o.v[0] = t.x; o.v[1] = t.y; o.v[2] = t.z; o.v[3] = t.w;
+  }
+}
+
+template <int G, bool KB, int NS>
+__global__ __launch_bounds__(1024) void attn_split_kernel(AttnDev p) {
+  constexpr int LPK = KVLane<KB>::LPK, DPL = KVLane<KB>::DPL, KPI = 64 / LPK;  // lanes per key, dims per lane, keys per wave-instruction
+  constexpr int PS = G * 64 + ATT_PS_PAD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nwaves = blockDim.x >> 6;
+  float* part = smem;                  // [16 waves][G][64]
+  float* stat = smem + 16 * G * 64;    // [16 waves][G][2] (max, sum)
+  const int row = blockIdx.x, h = blockIdx.y, prt = NS > 1 ? (int)blockIdx.z : 0;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int kk = lane / LPK, dl = lane % LPK;
+  const int pos = p.row_pos[row], slot = p.row_slot[row];
+  const int HD = p.n_q_heads * 64;
+  if (pos < 0 || pos >= p.cache_len) {  // nothing cached for this row: defined output, no OOB (every part returns: no ticket is taken)
+    if (prt == 0)
+      for (int i = tid; i < G * 16; i += blockDim.x) {
+        const int k = (h * G + (i >> 4)) * 64 + (i & 15) * 4;
+        if (p.out) *reinterpret_cast<float4*>(p.out + (long)row * HD + k) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.out_x3) x3_emit4(p.out_x3, row, k, HD >> 5, 0.f, 0.f, 0.f, 0.f);
+      }
+    return;
+  }
+  const int j_lo = (p.window > 0 && pos + 1 > p.window) ? pos + 1 - p.window : 0;
+  const int L = pos + 1 - j_lo;
+  // Short rows are not worth a hand-off (measured: the merge costs ~1 us per launch, the second workgroup buys nothing below a
+  // few hundred keys): part 0 then takes all the keys and writes the row itself, the other parts leave; nobody takes a ticket.
+  const bool shared = NS > 1 && L >= ATT_SPLIT_MIN_KEYS;
+  if (NS > 1 && !shared && prt != 0) return;
+  const int ns = shared ? NS : 1, my = shared ? prt : 0;
+  const long cbase = (((long)slot * p.n_kv_heads + h) * p.cache_len + j_lo) * 64;
+  const long ebase = cbase + dl * DPL;
+  const int step = KPI * nwaves * ns;
+
+  float qv[G][DPL];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const float* qp = p.q + (long)row * HD + (h * G + g) * 64 + dl * DPL;
+#pragma unroll
+    for (int i = 0; i < DPL; i += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(qp + i);
+      qv[g][i] = t.x * 0.125f; qv[g][i + 1] = t.y * 0.125f; qv[g][i + 2] = t.z * 0.125f; qv[g][i + 3] = t.w * 0.125f;
+    }
+  }
+  float mx[G], den[G], acc[G][DPL];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    mx[g] = -INFINITY; den[g] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) acc[g][i] = 0.f;
+  }
+
+  if constexpr (KB) {
+    // bf16 cache: the loaded rows stay packed (4 registers per key) and are widened where they are used -- K once per key for
+    // all G heads, V once per key for all G heads -- so that 1024 threads fit their 128 registers; 4 K + 4 V rows in flight per lane
+    constexpr int UNB = 4;
+    for (int j0 = (my * nwaves + wave) * KPI + kk; j0 < L + kk; j0 += step * UNB) {  // (+kk keeps the trip count wave-uniform)
+      uint4 kr[UNB], vr[UNB];
+#pragma unroll
+      for (int u = 0; u < UNB; ++u) {
+        const int j = j0 + u * step;
+        const bool ok = j < L;
+        kr[u] = ok ? *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.kc) + ebase + (long)j * 64) : make_uint4(0, 0, 0, 0);
+        vr[u] = ok ? *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.vc) + ebase + (long)j * 64) : make_uint4(0, 0, 0, 0);
+      }
+      float sc[G][UNB];
+#pragma unroll
+      for (int u = 0; u < UNB; ++u) {
+        const float kf[8] = {bf16_lo(kr[u].x), bf16_hi(kr[u].x), bf16_lo(kr[u].y), bf16_hi(kr[u].y),
+                             bf16_lo(kr[u].z), bf16_hi(kr[u].z), bf16_lo(kr[u].w), bf16_hi(kr[u].w)};
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          float t = qv[g][0] * kf[0];
+#pragma unroll
+          for (int i = 1; i < 8; ++i) t = fmaf(qv[g][i], kf[i], t);
+          t = group_sum<LPK>(t);
+          sc[g][u] = (j0 + u * step < L) ? t : -INFINITY;
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {  // one rescale per block of UNB keys
+        float bm = sc[g][0];
+#pragma unroll
+        for (int u = 1; u < UNB; ++u) bm = fmaxf(bm, sc[g][u]);
+        const float mn = fmaxf(mx[g], bm);
+        const float rs = mn > -INFINITY ? __expf(mx[g] - mn) : 1.f;  // exp(-inf - finite) = 0 on the first block
+        den[g] *= rs;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[g][i] *= rs;
+        mx[g] = mn;
+      }
+#pragma unroll
+      for (int u = 0; u < UNB; ++u) {
+        const float vf[8] = {bf16_lo(vr[u].x), bf16_hi(vr[u].x), bf16_lo(vr[u].y), bf16_hi(vr[u].y),
+                             bf16_lo(vr[u].z), bf16_hi(vr[u].z), bf16_lo(vr[u].w), bf16_hi(vr[u].w)};
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float e = mx[g] > -INFINITY ? __expf(sc[g][u] - mx[g]) : 0.f;  // masked keys: exp(-inf) = 0
+          den[g] += e;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[g][i] = fmaf(e, vf[i], acc[g][i]);
+        }
+      }
+    }
+  } else {
+  for (int j0 = (my * nwaves + wave) * KPI + kk; j0 < L + kk; j0 += step * ATT_UN) {  // (+kk keeps the trip count wave-uniform)
+    KVLane<KB> kv[ATT_UN], vv[ATT_UN];
+#pragma unroll
+    for (int u = 0; u < ATT_UN; ++u) {
+      const int j = j0 + u * step;
+      load_kv_lane<KB>(p.kc, ebase + (long)j * 64, j < L, kv[u]);
+      load_kv_lane<KB>(p.vc, ebase + (long)j * 64, j < L, vv[u]);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float sc[ATT_UN];
+      float bm = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < ATT_UN; ++u) {
+        float t = qv[g][0] * kv[u].v[0];
+#pragma unroll
+        for (int i = 1; i < DPL; ++i) t = fmaf(qv[g][i], kv[u].v[i], t);
+        t = group_sum<LPK>(t);
+        sc[u] = (j0 + u * step < L) ? t : -INFINITY;
+        bm = fmaxf(bm, sc[u]);
+      }
+      if (bm > -INFINITY) {  // uniform inside the lane group
+        const float mn = fmaxf(mx[g], bm);
+        const float rs = __expf(mx[g] - mn);  // exp(-inf) = 0 on the first block
+        float d = den[g] * rs;
+        float a[DPL];
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) a[i] = acc[g][i] * rs;
+#pragma unroll
+        for (int u = 0; u < ATT_UN; ++u) {
+          const float e = __expf(sc[u] - mn);  // masked keys: exp(-inf) = 0
+          d += e;
+#pragma unroll
+          for (int i = 0; i < DPL; ++i) a[i] = fmaf(e, vv[u].v[i], a[i]);
+        }
+        mx[g] = mn; den[g] = d;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) acc[g][i] = a[i];
+      }
+    }
+  }
+
+  }
+
+  // ---- merge the KPI lane groups of the wave (fixed order: xor LPK, 2 LPK, .. 32)
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+#pragma unroll
+    for (int o = LPK; o <= 32; o <<= 1) {
+      const float om = __shfl_xor(mx[g], o), od = __shfl_xor(den[g], o);
+      const float mn = fmaxf(mx[g], om);
+      const float sa = mn > -INFINITY ? __expf(mx[g] - mn) : 0.f, sb = mn > -INFINITY ? __expf(om - mn) : 0.f;
+      den[g] = den[g] * sa + od * sb;
+#pragma unroll
+      for (int i = 0; i < DPL; ++i) acc[g][i] = acc[g][i] * sa + __shfl_xor(acc[g][i], o) * sb;
+      mx[g] = mn;
+    }
+    if (kk == 0) {
+#pragma unroll
+      for (int i = 0; i < DPL; i += 4)
+        *reinterpret_cast<float4*>(part + (wave * G + g) * 64 + dl * DPL + i) = make_float4(acc[g][i], acc[g][i + 1], acc[g][i + 2], acc[g][i + 3]);
+    }
+    if (lane == 0) { stat[(wave * G + g) * 2] = mx[g]; stat[(wave * G + g) * 2 + 1] = den[g]; }
+  }
+  __syncthreads();
+  if (tid >= 64) return;  // everything below happens inside wave 0 (G * 16 <= 64 lanes carry data)
+  // ---- merge the waves
+  const bool on = tid < G * 16;
+  const int g = on ? tid >> 4 : 0, d4 = (tid & 15) * 4;
+  float gm = -INFINITY;
+  for (int w = 0; w < nwaves; ++w) gm = fmaxf(gm, stat[(w * G + g) * 2]);
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dsum = 0.f;
+  for (int w = 0; w < nwaves; ++w) {
+    const float wm = stat[(w * G + g) * 2];
+    const float sc = wm > -INFINITY ? __expf(wm - gm) : 0.f;
+    const float4 t = *reinterpret_cast<const float4*>(part + (w * G + g) * 64 + d4);
+    sum.x = fmaf(t.x, sc, sum.x); sum.y = fmaf(t.y, sc, sum.y); sum.z = fmaf(t.z, sc, sum.z); sum.w = fmaf(t.w, sc, sum.w);
+    dsum = fmaf(stat[(w * G + g) * 2 + 1], sc, dsum);
+  }
+  if (shared) {
+    // ---- publish this part's record, take a ticket; the workgroup that completes the pair merges all parts in part order
+    const int pair = row * p.n_kv_heads + h;
+    const unsigned rec_bytes = (unsigned)((size_t)gridDim.x * p.n_kv_heads * NS * PS * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.split_part, 0, rec_bytes, 0x00020000);
+    const unsigned rec0 = (unsigned)(((size_t)pair * NS) * PS * sizeof(float));
+    if (on) {
+      typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+      typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+      u32x4s sv; sv[0] = __float_as_uint(sum.x); sv[1] = __float_as_uint(sum.y); sv[2] = __float_as_uint(sum.z); sv[3] = __float_as_uint(sum.w);
+      __builtin_amdgcn_raw_buffer_store_b128(sv, rr, rec0 + (unsigned)((prt * PS + g * 64 + d4) * 4), 0, 16);  // aux 16 = sc1 (write-through)
+      if ((tid & 15) == 0) {
+        u32x2s mv; mv[0] = __float_as_uint(gm); mv[1] = __float_as_uint(dsum);
+        __builtin_amdgcn_raw_buffer_store_b64(mv, rr, rec0 + (unsigned)((prt * PS + G * 64 + g * 2) * 4), 0, 16);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the one storing wave has drained before its lane 0 signals
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(p.split_ticket + pair, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (((old + 1) % NS) != 0) return;  // not the last arriver of this launch
+    typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+    float pm[NS], pd[NS];
+    float4 ps[NS];
+    float gm2 = -INFINITY;
+#pragma unroll
+    for (int q2 = 0; q2 < NS; ++q2) {  // every record through sc1 loads, this workgroup's own included: same bits whoever merges
+      const u32x2s mv = __builtin_amdgcn_raw_buffer_load_b64(rr, rec0 + (unsigned)((q2 * PS + G * 64 + g * 2) * 4), 0, 16);
+      const u32x4s sv = __builtin_amdgcn_raw_buffer_load_b128(rr, rec0 + (unsigned)((q2 * PS + g * 64 + d4) * 4), 0, 16);
+      pm[q2] = __uint_as_float(mv[0]); pd[q2] = __uint_as_float(mv[1]);
+      ps[q2] = make_float4(__uint_as_float(sv[0]), __uint_as_float(sv[1]), __uint_as_float(sv[2]), __uint_as_float(sv[3]));
+      gm2 = fmaxf(gm2, pm[q2]);
+    }
+    sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    dsum = 0.f;
+#pragma unroll
+    for (int q2 = 0; q2 < NS; ++q2) {
+      const float sc = pm[q2] > -INFINITY ? __expf(pm[q2] - gm2) : 0.f;
+      sum.x = fmaf(ps[q2].x, sc, sum.x); sum.y = fmaf(ps[q2].y, sc, sum.y); sum.z = fmaf(ps[q2].z, sc, sum.z); sum.w = fmaf(ps[q2].w, sc, sum.w);
+      dsum = fmaf(pd[q2], sc, dsum);
+    }
+  }
+  if (on) {
     const float inv = 1.0f / dsum;
     const int k = (h * G + g) * 64 + d4;
     // rounded once (no contraction into the X3 split): the fp32 and the X3 outputs are the same numbers
@@ -428,7 +704,7 @@ __global__ __launch_bounds__(256) void attn_short_kernel(AttnDev p, int n_pairs)
 
 int launch_attention(const float* q, const void* kc, const void* vc, const int32_t* row_pos, const int32_t* row_slot,
                      int n_rows, int n_q_heads, int n_kv_heads, int cache_len, int window, float* out, void* out_x3,
-                     hipStream_t stream, int kv_format, int iota_pos) {
+                     hipStream_t stream, int kv_format, int iota_pos, float* split_part, int32_t* split_ticket) {
   ST_REQUIRE(kv_format == SMOLTTS_KV_F32 || (kv_format == SMOLTTS_KV_BF16 && cache_len > 16), SMOLTTS_E_INVALID,
              "attention: kv_format %d unsupported here (bf16 caches need more than 16 entries)", kv_format);
   const bool kb = kv_format == SMOLTTS_KV_BF16;
@@ -436,7 +712,7 @@ int launch_attention(const float* q, const void* kc, const void* vc, const int32
   ST_REQUIRE(n_rows > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0 && cache_len > 0, SMOLTTS_E_INVALID,
              "attention: bad shape rows=%d q_heads=%d kv_heads=%d cache_len=%d", n_rows, n_q_heads, n_kv_heads, cache_len);
   const int G = n_q_heads / n_kv_heads;
-  AttnDev d{q, kc, vc, row_pos, row_slot, out, (char*)out_x3, n_q_heads, n_kv_heads, cache_len, window, 0, -1};
+  AttnDev d{q, kc, vc, row_pos, row_slot, out, (char*)out_x3, n_q_heads, n_kv_heads, cache_len, window, 0, -1, split_part, split_ticket};
   if (iota_pos >= 0 && cache_len <= 16) d.iota_pos = iota_pos;  // (only the short-cache kernel takes it)
   d.score_cap = (window > 0 && window < cache_len) ? window : cache_len;
   d.score_cap = (d.score_cap + 3) & ~3;
@@ -476,6 +752,33 @@ int launch_attention(const float* q, const void* kc, const void* vc, const int32
     const dim3 pgrid((unsigned)(((units + 7) / 8) * 8 * members));
     if (kb) hipLaunchKernelGGL((attn_prefill_kernel<1, true>), pgrid, dim3(256), 0, stream, d, n_rows, nx);
     else hipLaunchKernelGGL((attn_prefill_kernel<1, false>), pgrid, dim3(256), 0, stream, d, n_rows, nx);
+    ST_CHECK_HIP(hipGetLastError());
+    return SMOLTTS_OK;
+  }
+  // Few (row, kv head) pairs over a long cache (the decode frame's slow attention at B <= 32): the keys of a pair go to two
+  // workgroups so that all CUs stream the cache, merged inside the launch (attn_split_kernel); a bf16 cache always takes that
+  // kernel (8 lanes per key).  The caller provides the records / tickets (sized for ATT_SPLIT_MAX_PAIRS pairs).
+  const bool can_split = split_part && split_ticket && (long)n_rows * n_kv_heads <= ATT_SPLIT_MAX_PAIRS && d.score_cap > 128 && nwaves == 16;
+  if (kb || can_split) {
+    const int NS = can_split ? 2 : 1;
+    const dim3 sgrid(n_rows, n_kv_heads, NS);
+#define ST_SPLIT(GG)                                                                                                              \
+  case GG:                                                                                                                          \
+    if (kb && NS == 2) hipLaunchKernelGGL((attn_split_kernel<GG, true, 2>), sgrid, dim3(nwaves * 64), lds, stream, d);              \
+    else if (kb) hipLaunchKernelGGL((attn_split_kernel<GG, true, 1>), sgrid, dim3(nwaves * 64), lds, stream, d);                    \
+    else hipLaunchKernelGGL((attn_split_kernel<GG, false, 2>), sgrid, dim3(nwaves * 64), lds, stream, d);                           \
+    break;
+    ST_REQUIRE(lds <= 64 * 1024, SMOLTTS_E_CAPACITY, "attention: %zu bytes of LDS", lds);
+    switch (G) {
+      ST_SPLIT(1)
+      ST_SPLIT(2)
+      ST_SPLIT(3)
+      ST_SPLIT(4)
+      default:
+        set_error("attention: GQA group size %d not instantiated (1..4)", G);
+        return SMOLTTS_E_INVALID;
+    }
+#undef ST_SPLIT
     ST_CHECK_HIP(hipGetLastError());
     return SMOLTTS_OK;
   }

@@ -59,6 +59,8 @@ struct SmolttsSession {
   int* salt;                   // [B] tenants a slot has had: mixed into the sampling seed
   int *stage_slots, *stage_last;                     // [B]
   float* margin;             // [B]
+  float* attn_part;          // key-split slow attention: partial records (ATT_SPLIT_PART_FLOATS)
+  int* attn_ticket;          // ... and arrival tickets [ATT_SPLIT_MAX_PAIRS], counting up from 0 (zeroed once, at creation)
   int* margin_at;            // [B] frame * 64 + step of the slot's smallest top-2 gap
   int* codes;                // [B][max_frames][1+n_fast]
   // host staging (pinned)
@@ -87,6 +89,7 @@ struct SmolttsSession {
   int dup_code, dup_n;
   bool use_qkv_table;          // depth layer-0 q | k | v from the engine's table where it exists (SMOLTTS_OPT_QKV_TABLE)
   bool commit_picks;           // slow token and last depth code picked inside the commit kernel (SMOLTTS_OPT_COMMIT_PICKS)
+  bool split_attn;             // slow attention of few rows over two workgroups per (row, kv head) (SMOLTTS_OPT_SPLIT_ATTN)
 };
 
 namespace {
@@ -143,14 +146,17 @@ void carve(SmolttsSession* s, char* base, size_t* total) {
   s->stage_slots = cv.take<int>(B);
   s->stage_last = cv.take<int>(B);
   s->margin = cv.take<float>(B);
+  s->attn_part = cv.take<float>(ATT_SPLIT_PART_FLOATS);
+  s->attn_ticket = cv.take<int>(ATT_SPLIT_MAX_PAIRS);
   s->margin_at = cv.take<int>(B);
   s->codes = cv.take<int>(B * (size_t)s->max_frames * H);
   *total = cv.off;
 }
 
 __global__ void init_state_kernel(int B, int n_fast, int* iota, int* fastpos, int* pos, int* frames, int* done, int* mask,
-                                  float* margin, int* margin_at, int* cur_col, int* new_col, int* salt) {
+                                  float* margin, int* margin_at, int* cur_col, int* new_col, int* salt, int* attn_ticket) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int i = b; i < ATT_SPLIT_MAX_PAIRS; i += gridDim.x * blockDim.x) attn_ticket[i] = 0;
   if (b >= B) return;
   margin_at[b] = 0;
   iota[b] = b;
@@ -310,7 +316,8 @@ int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, i
   if (!first_pos) {
     const int reps = dup_hit(s, cache_len <= 16 ? 100 : 101, 0) ? 2 : 1;
     for (int i = 0; i < reps; ++i)
-      ST_TRY(launch_attention(q, kc, vc, row_pos, row_slot, M, n_head, n_kv, cache_len, 0, nullptr, s->x3a, st, kv_format, iota_pos));
+      ST_TRY(launch_attention(q, kc, vc, row_pos, row_slot, M, n_head, n_kv, cache_len, 0, nullptr, s->x3a, st, kv_format, iota_pos,
+                              s->split_attn ? s->attn_part : nullptr, s->attn_ticket));
   }
   {  // x += attn . Wo^T ; publish x * ffn_norm for w1|w3
     SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.wo, s->x3a, M, dim, dim, SMOLTTS_EPI_RESID);
@@ -721,6 +728,7 @@ int smoltts_session_create_kv(SmolttsEngine* e, void* slab_dev, size_t slab_byte
   s->dup_code = -1;
   s->use_qkv_table = true;
   s->commit_picks = true;
+  s->split_attn = true;
   s->kv_format = kv_format;
   size_t total = 0;
   carve(s, (char*)slab_dev, &total);
@@ -753,7 +761,7 @@ int smoltts_session_create_kv(SmolttsEngine* e, void* slab_dev, size_t slab_byte
     s->flight_limit = limit;
   }
   hipLaunchKernelGGL(init_state_kernel, dim3((max_batch + 63) / 64), dim3(64), 0, 0, max_batch, e->cfg.n_fast, s->iota,
-                     s->fastpos, s->pos, s->frames, s->done, s->mask, s->margin, s->margin_at, s->cur_col, s->new_col, s->salt);
+                     s->fastpos, s->pos, s->frames, s->done, s->mask, s->margin, s->margin_at, s->cur_col, s->new_col, s->salt, s->attn_ticket);
   hipError_t err = hipGetLastError();
   if (err == hipSuccess) err = hipStreamSynchronize(0);
   if (err != hipSuccess) {
@@ -949,6 +957,7 @@ int smoltts_session_set_option(SmolttsSession* s, int32_t option, int32_t value)
   switch (option) {
     case SMOLTTS_OPT_QKV_TABLE: s->use_qkv_table = value != 0; break;
     case SMOLTTS_OPT_COMMIT_PICKS: s->commit_picks = value != 0; break;
+    case SMOLTTS_OPT_SPLIT_ATTN: s->split_attn = value != 0; break;
     default:
       set_error("session_set_option: unknown option %d", option);
       return SMOLTTS_E_INVALID;

@@ -104,7 +104,7 @@ _EXPORTS = [
     "smoltts_mimi_slab_bytes", "smoltts_mimi_session_create", "smoltts_mimi_session_destroy", "smoltts_mimi_reset",
     "smoltts_mimi_decode_chunk", "smoltts_k_gemm", "smoltts_k_attention", "smoltts_k_embed", "smoltts_k_argmax",
     "smoltts_k_layernorm", "smoltts_k_gemm3", "smoltts_k_x3_pack",
-    "smoltts_session_measure_duplicate", "smoltts_session_margin_at", "smoltts_session_drop_graph", "smoltts_session_set_frames_per_graph", "smoltts_engine_fast_qkv_bytes", "smoltts_engine_build_fast_qkv", "smoltts_session_set_option",
+    "smoltts_session_measure_duplicate", "smoltts_session_margin_at", "smoltts_session_drop_graph", "smoltts_session_set_frames_per_graph", "smoltts_engine_fast_qkv_bytes", "smoltts_engine_build_fast_qkv", "smoltts_session_set_option", "smoltts_k_attention_split",
     "smoltts_session_slab_bytes_kv", "smoltts_session_create_kv", "smoltts_k_attention_kv", "smoltts_session_set_sampling", "smoltts_k_sample",
     "smoltts_lm_prefill_chunk", "smoltts_lm_prefill_deferred", "smoltts_mimi_reset_slots", "smoltts_mimi_encoder_create", "smoltts_mimi_encoder_destroy", "smoltts_mimi_encode_frames",
     "smoltts_mimi_encode_workspace_bytes", "smoltts_mimi_encode",
@@ -172,6 +172,7 @@ def load_library(path: Optional[Path] = None):
     lib.smoltts_engine_fast_qkv_bytes.restype = C.c_size_t
     lib.smoltts_engine_build_fast_qkv.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.smoltts_session_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.smoltts_k_attention_split.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.smoltts_mimi_reset_slots.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.smoltts_lm_prefill_deferred.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                                 C.c_int32, C.c_void_p]
@@ -290,7 +291,7 @@ def _fill_block(dst: BlockWeights, src: Dict[str, int]) -> None:
         setattr(dst, k, v)
 
 
-OPT_QKV_TABLE, OPT_COMMIT_PICKS = 1, 2  # include/smoltts_hip.h SMOLTTS_OPT_*
+OPT_QKV_TABLE, OPT_COMMIT_PICKS, OPT_SPLIT_ATTN = 1, 2, 3  # include/smoltts_hip.h SMOLTTS_OPT_*
 
 
 class LMEngine:
@@ -397,8 +398,10 @@ class LMSession:
         check(self.lib.smoltts_session_margin_at(h, C.byref(mp)), "smoltts_session_margin_at")
         self.margin_at = view(mp, self.B * 4, torch.int32, (self.B,))  # frame * 64 + step of each slot's smallest gap
         self._keep = None
-        if os.environ.get("SMOLTTS_COMMIT_PICKS") == "0":  # A/B switch of tools/ (the ids are the same either way)
+        if os.environ.get("SMOLTTS_COMMIT_PICKS") == "0":  # A/B switches of tools/ (the ids are the same either way)
             self.use_commit_picks(False)
+        if os.environ.get("SMOLTTS_SPLIT_ATTN") == "0":
+            self.use_split_attention(False)
 
     def prefill(self, prompts: Sequence[np.ndarray], slots: Optional[Sequence[int]] = None, stop_on_eos: bool = True,
                 pos0: Optional[Sequence[int]] = None, final: bool = True, defer_frame0: bool = False) -> None:
@@ -479,6 +482,10 @@ class LMSession:
     def use_qkv_table(self, on: bool) -> None:
         """Depth layer-0 q | k | v from the engine's table (default where it exists) or through the wqkv GEMM (A/B, tests)."""
         check(self.lib.smoltts_session_set_option(self.handle, OPT_QKV_TABLE, 1 if on else 0), "smoltts_session_set_option")
+
+    def use_split_attention(self, on: bool) -> None:
+        """Slow attention of few rows with the keys of a (row, kv head) pair on two workgroups (default) or on one."""
+        check(self.lib.smoltts_session_set_option(self.handle, OPT_SPLIT_ATTN, 1 if on else 0), "smoltts_session_set_option")
 
     def use_commit_picks(self, on: bool) -> None:
         """The frame's slow token and last depth code picked inside the commit kernel (default) or in launches of their own."""

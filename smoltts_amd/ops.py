@@ -81,6 +81,25 @@ def attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, row
     return out
 
 
+SPLIT_PART_FLOATS, SPLIT_TICKETS = 128 * 2 * (4 * 64 + 8), 128  # csrc/common.h ATT_SPLIT_*
+
+
+def attention_split(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, row_pos: torch.Tensor, row_slot: torch.Tensor,
+                    n_q_heads: int, scratch, window: int = 0, out_x3: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``attention`` with the keys of every (row, kv head) pair on two workgroups (rows x kv heads <= 128, cache_len > 128).
+    ``scratch`` = (part fp32 [SPLIT_PART_FLOATS], ticket int32 [SPLIT_TICKETS] zeroed once and then left alone)."""
+    lib = E.load_library()
+    n_kv, cache_len = k_cache.shape[1], k_cache.shape[2]
+    part, ticket = scratch
+    assert part.numel() >= SPLIT_PART_FLOATS and ticket.numel() >= SPLIT_TICKETS and ticket.dtype == torch.int32
+    out = torch.empty_like(q)
+    E.check(lib.smoltts_k_attention_split(E.dptr(q), E.dptr(k_cache), E.dptr(v_cache), E.dptr(row_pos), E.dptr(row_slot),
+                                          q.shape[0], n_q_heads, n_kv, cache_len, window, E.dptr(out), E.dptr(out_x3),
+                                          1 if k_cache.dtype == torch.bfloat16 else 0, E.dptr(part), E.dptr(ticket),
+                                          E.current_stream_ptr()), "smoltts_k_attention_split")
+    return out
+
+
 def embed(cols: torch.Tensor, text_emb: torch.Tensor, cb_emb: torch.Tensor, codebook_size: int, cb_first_offset: int = 0,
           mask_mode: int = 0, sem_start: int = 320, sem_end: int = 2367) -> torch.Tensor:
     """cols int32 [rows, 1+n]; bf16 tables; -> fp32 [rows, dim]."""

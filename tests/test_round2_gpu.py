@@ -100,7 +100,10 @@ def test_attention_over_a_bf16_cache(Hq, Hkv):
             V = vc[s, :, : p + 1].float().repeat_interleave(G, dim=0)
             a = torch.softmax(q[r].view(Hq, 1, 64) @ K.transpose(1, 2) / 8.0, dim=-1) @ V
             assert float((out[r] - a.reshape(-1)).abs().max() / a.abs().max()) < 2e-5, (rows, r, p)
-        assert torch.equal(out, ref32)  # same kernels, same arithmetic: only the storage of K/V differs
+        if rows >= 256:
+            assert torch.equal(out, ref32)  # the prefill kernel: same arithmetic, only the storage of K/V differs
+        else:  # decode: a bf16 cache is read 8 lanes per key (attn_split_kernel), an fp32 one 16: fp32 sums in another order
+            assert float((out - ref32).abs().max() / ref32.abs().max()) < 2e-6
 
 
 @pytest.mark.parametrize("cfgname,B,F", [("tiny", 4, 16), ("smoltts_byte_70m", 3, 10)])
