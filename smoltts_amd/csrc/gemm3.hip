@@ -127,10 +127,15 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
   constexpr int kPieces = kResid ? SMOLTTS_DBG_PIECES_RESID : SMOLTTS_DBG_PIECES;  // 3 in the product
   STAMP3(0);
 
-  const bool fin = wave < MT;  // waves that will finish the tiles
-  const int m = (mg * MT + wave) * 16 + r;  // meaningful for fin waves only
+  // Finishing waves: one per (column tile, row tile) of the workgroup -- wave f finishes tile tf = f / MT of row tile f % MT, so
+  // the T tile epilogues of a workgroup (w1|w3: three SwiGLU tiles) run side by side on different SIMDs instead of one after
+  // the other in wave 0.  Each loads the epilogue inputs of ITS tile only (the same loads in total); the RMSNorm row scale is
+  // worked out once per row tile, by tile 0's finisher, and handed over through LDS (no second read of the sums of squares).
+  constexpr int NF = MT * T;
+  const bool fin = wave < NF;
+  const int fmt = wave % MT, tf = fin ? wave / MT : 0;
+  const int m = (mg * MT + fmt) * 16 + r;  // meaningful for fin waves only
   const bool mvalid = fin && m < p.M && row_on;
-
   f32x4 acc[T][MT];
   const char* xb[MT];
   bool xv[MT];
@@ -177,14 +182,17 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
   // kernel waits on nothing
   int pos = 0, slot = 0;
   float ssv[16];
-  float4 rr[T], bb[T], ga[T], gb[T], ws[T];
+  float4 rr, bb, ga, gb, ws;
+  rr = bb = make_float4(0.f, 0.f, 0.f, 0.f);
+  ga = gb = ws = make_float4(1.f, 1.f, 1.f, 1.f);
+  const bool norm_wave = fin && tf == 0;  // reads the sums of squares of its row tile
   if (fin) {  // wave-uniform branches, clamped (always valid) addresses: no per-lane control flow
     const int mc = m < p.M ? m : p.M - 1;
     if (kRope) { pos = p.row_pos[mc]; slot = p.row_slot[mc]; }
     const int nt_in = p.K >> 4;
 #pragma unroll
     for (int j = 0; j < 16; ++j) ssv[j] = 0.f;
-    if (p.ssq_in != nullptr) {
+    if (p.ssq_in != nullptr && norm_wave) {
       const float* sp = p.ssq_in + (size_t)mc * nt_in;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
@@ -193,17 +201,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
         ssv[j] = i < nt_in ? vld : 0.f;
       }
     }
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const int n0r = (ng * T + t) * 16 + q * 4;
+    {
+      const int n0r = (ng * T + tf) * 16 + q * 4;
       const int n0 = n0r < p.N ? n0r : p.N - 4;  // N % 4 == 0
-      rr[t] = bb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-      ga[t] = gb[t] = ws[t] = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (W8) ws[t] = *reinterpret_cast<const float4*>(p.wscale + n0);
-      if (kResid) rr[t] = *reinterpret_cast<const float4*>(p.resid + (long)mc * p.ldo + n0);
-      if (p.bias != nullptr) bb[t] = *reinterpret_cast<const float4*>(p.bias + n0);
-      if (kEmits && p.emit.x3a && p.emit.gamma_a) ga[t] = *reinterpret_cast<const float4*>(p.emit.gamma_a + n0);
-      if (kEmits && p.emit.x3b && p.emit.gamma_b) gb[t] = *reinterpret_cast<const float4*>(p.emit.gamma_b + n0);
+      if (W8) ws = *reinterpret_cast<const float4*>(p.wscale + n0);
+      if (kResid) rr = *reinterpret_cast<const float4*>(p.resid + (long)mc * p.ldo + n0);
+      if (p.bias != nullptr) bb = *reinterpret_cast<const float4*>(p.bias + n0);
+      if (kEmits && p.emit.x3a && p.emit.gamma_a) ga = *reinterpret_cast<const float4*>(p.emit.gamma_a + n0);
+      if (kEmits && p.emit.x3b && p.emit.gamma_b) gb = *reinterpret_cast<const float4*>(p.emit.gamma_b + n0);
     }
   }
 
@@ -228,14 +233,11 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
 
   STAMP3(1);
   // RoPE rows of the finishing waves (needs pos, which arrived long ago); in flight across the barrier
-  float4 cs[T];
+  float4 cs = make_float4(1.f, 0.f, 1.f, 0.f);
   if (kRope && fin) {
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const int n0 = (ng * T + t) * 16 + q * 4;
-      const bool rot = mvalid && n0 < (p.n_q_heads + p.n_kv_heads) * 64 && pos >= 0 && pos < p.cache_len;  // the table has >= cache_len rows
-      cs[t] = rot ? *reinterpret_cast<const float4*>(p.rope + ((long)pos * 32 + ((n0 & 63) >> 1)) * 2) : make_float4(1.f, 0.f, 1.f, 0.f);
-    }
+    const int n0 = (ng * T + tf) * 16 + q * 4;
+    const bool rot = mvalid && n0 < (p.n_q_heads + p.n_kv_heads) * 64 && pos >= 0 && pos < p.cache_len;  // the table has >= cache_len rows
+    if (rot) cs = *reinterpret_cast<const float4*>(p.rope + ((long)pos * 32 + ((n0 & 63) >> 1)) * 2);
   }
 
   // ---- cross-wave reduction: red4[((wave*T + t)*MT + mt)*64 + lane]
@@ -246,29 +248,32 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
     for (int mt = 0; mt < MT; ++mt)
       red4[((wave * T + t) * MT + mt) * 64 + lane] = make_float4(acc[t][mt][0], acc[t][mt][1], acc[t][mt][2], acc[t][mt][3]);
   }
+  // RMSNorm row scale from the producer's partial sums of squares (fixed order), by the row tile's first finisher, before the
+  // barrier: the other finishers of the row tile pick it up from LDS behind it
+  float* rstd_lds = smem + (size_t)nwaves * T * MT * 256;  // [MT][16] behind the partial tiles
+  float rstd = 1.f;
+  if (p.ssq_in != nullptr && norm_wave) {
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sq += ssv[j];
+    const int nt_in = p.K >> 4;
+    if (nt_in > 64 && mvalid)
+      for (int i = 64 + q; i < nt_in; i += 4) sq += p.ssq_in[(size_t)m * nt_in + i];
+    sq += __shfl_xor(sq, 16);
+    sq += __shfl_xor(sq, 32);
+    rstd = 1.0f / sqrtf(sq / (float)p.K + p.eps);
+    if (NF > MT && q == 0) rstd_lds[fmt * 16 + r] = rstd;
+  }
   STAMP3(2);
   __syncthreads();
   STAMP3(3);
   if (!fin) return;
-  const int mt = wave;  // lane, r, q keep their meaning
-
-  // RMSNorm row scale from the producer's partial sums of squares (fixed order)
-  float rstd = 1.f;
-  if (p.ssq_in != nullptr) {
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) s += ssv[j];
-    const int nt_in = p.K >> 4;
-    if (nt_in > 64 && mvalid)
-      for (int i = 64 + q; i < nt_in; i += 4) s += p.ssq_in[(size_t)m * nt_in + i];
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    rstd = 1.0f / sqrtf(s / (float)p.K + p.eps);
-  }
+  const int mt = fmt;  // lane, r, q keep their meaning
+  if (NF > MT && p.ssq_in != nullptr && !norm_wave) rstd = rstd_lds[fmt * 16 + r];
   if (kRope && !mvalid) pos = -1;
 
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
+  {
+    const int t = tf;
     float4 part[8];  // workgroups have at most 8 waves (launch3_epi)
 #pragma unroll
     for (int w = 0; w < 8; ++w) part[w] = red4[(((w < nwaves ? w : 0) * T + t) * MT + mt) * 64 + lane];
@@ -284,21 +289,21 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
     const int ntile = ng * T + t;
     const int n0 = ntile * 16 + q * 4;
     const bool valid = mvalid && n0 < p.N;  // N % 4 == 0
-    if (W8) { v[0] *= ws[t].x; v[1] *= ws[t].y; v[2] *= ws[t].z; v[3] *= ws[t].w; }
-    v[0] = v[0] * rstd + bb[t].x; v[1] = v[1] * rstd + bb[t].y; v[2] = v[2] * rstd + bb[t].z; v[3] = v[3] * rstd + bb[t].w;
+    if (W8) { v[0] *= ws.x; v[1] *= ws.y; v[2] *= ws.z; v[3] *= ws.w; }
+    v[0] = v[0] * rstd + bb.x; v[1] = v[1] * rstd + bb.y; v[2] = v[2] * rstd + bb.z; v[3] = v[3] * rstd + bb.w;
 
     if (EPI == SMOLTTS_EPI_STORE || EPI == SMOLTTS_EPI_RESID) {
-      if (kResid) { v[0] += rr[t].x; v[1] += rr[t].y; v[2] += rr[t].z; v[3] += rr[t].w; }
+      if (kResid) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
       if (valid) {
         *reinterpret_cast<float4*>(p.out + (long)m * p.ldo + n0) = make_float4(v[0], v[1], v[2], v[3]);
-        if (p.emit.x3a) x3_emit4(p.emit.x3a, m, n0, p.N >> 5, v[0] * ga[t].x, v[1] * ga[t].y, v[2] * ga[t].z, v[3] * ga[t].w);
-        if (p.emit.x3b) x3_emit4(p.emit.x3b, m, n0, p.N >> 5, v[0] * gb[t].x, v[1] * gb[t].y, v[2] * gb[t].z, v[3] * gb[t].w);
+        if (p.emit.x3a) x3_emit4(p.emit.x3a, m, n0, p.N >> 5, v[0] * ga.x, v[1] * ga.y, v[2] * ga.z, v[3] * ga.w);
+        if (p.emit.x3b) x3_emit4(p.emit.x3b, m, n0, p.N >> 5, v[0] * gb.x, v[1] * gb.y, v[2] * gb.z, v[3] * gb.w);
       }
       if (p.emit.ssq) {  // all 64 lanes take part in the shuffles
-        float s = valid ? ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) : 0.f;
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        if (q == 0 && mvalid && ntile * 16 < p.N) p.emit.ssq[(size_t)m * (p.N >> 4) + ntile] = s;
+        float sq = valid ? ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) : 0.f;
+        sq += __shfl_xor(sq, 16);
+        sq += __shfl_xor(sq, 32);
+        if (q == 0 && mvalid && ntile * 16 < p.N) p.emit.ssq[(size_t)m * (p.N >> 4) + ntile] = sq;
       }
     } else if (EPI == SMOLTTS_EPI_SWIGLU) {
       if (valid) x3_emit2(p.x3_out, m, n0 >> 1, p.N >> 6, silu3(v[0]) * v[1], silu3(v[2]) * v[3]);
@@ -306,8 +311,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
       if (valid) {
         const int qd = p.n_q_heads * 64, kd = p.n_kv_heads * 64;
         if (n0 < qd + kd) {
-          const float o0 = v[0] * cs[t].x - v[1] * cs[t].y, o1 = v[1] * cs[t].x + v[0] * cs[t].y;
-          const float o2 = v[2] * cs[t].z - v[3] * cs[t].w, o3 = v[3] * cs[t].z + v[2] * cs[t].w;
+          const float o0 = v[0] * cs.x - v[1] * cs.y, o1 = v[1] * cs.x + v[0] * cs.y;
+          const float o2 = v[2] * cs.z - v[3] * cs.w, o3 = v[3] * cs.z + v[2] * cs.w;
           v[0] = o0; v[1] = o1; v[2] = o2; v[3] = o3;
         }
         const float4 o = make_float4(v[0], v[1], v[2], v[3]);
@@ -497,9 +502,9 @@ static int launch3_rows(const Gemm3Dev& d, hipStream_t stream) {
 template <int MT, int T, int U, int EPI, bool W8>
 static int launch3_one(const Gemm3Dev& d, int nwaves, hipStream_t stream) {
   const int ntiles = (d.N + 15) / 16;
-  if (nwaves < MT) nwaves = MT;  // one finishing wave per 16-row tile
+  if (nwaves < MT * T) nwaves = MT * T;  // one finishing wave per (column tile, row tile) of the workgroup
   const dim3 grid((ntiles + T - 1) / T, ((d.M + 16 * MT - 1) / (16 * MT)) * (d.half_rows ? 2 : 1));
-  const size_t lds = (size_t)nwaves * T * MT * 1024;
+  const size_t lds = (size_t)nwaves * T * MT * 1024 + (size_t)MT * 16 * sizeof(float);  // partial tiles + the row scales
   hipLaunchKernelGGL((gemm3_kernel<MT, T, U, EPI, W8>), grid, dim3(nwaves * 64), lds, stream, d);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
