@@ -640,18 +640,21 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnDev p, int n_rows
 // memory round trip plus wave shuffles.
 template <int G, int UN>
 __global__ __launch_bounds__(256) void attn_short_kernel(AttnDev p, int n_pairs) {
+  // one wave per (row, QUERY head): the G heads of a kv group used to be worked off one after the other inside one wave -- three
+  // softmaxes in a row on the critical path of a launch that is nothing but latency; each wave now loads its kv head's <= 16
+  // K / V rows itself (L2 hits: the G waves of a group sit in the same workgroup or the next) and does one head
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int kk = lane >> 4, dl = lane & 15;
-  const int pair = blockIdx.x * 4 + wave;
+  const int pair = blockIdx.x * 4 + wave;  // (row, query head)
   if (pair >= n_pairs) return;
-  const int row = pair / p.n_kv_heads, h = pair - row * p.n_kv_heads;
+  const int row = pair / p.n_q_heads, hq = pair - row * p.n_q_heads, h = hq / G;
   const int pos = p.iota_pos >= 0 ? p.iota_pos : p.row_pos[row], slot = p.iota_pos >= 0 ? row : p.row_slot[row];
   const int HD = p.n_q_heads * 64;
   const bool ok = pos >= 0 && pos < p.cache_len;
   const int j_lo = (ok && p.window > 0 && pos + 1 > p.window) ? pos + 1 - p.window : 0;
   const int L = ok ? pos + 1 - j_lo : 0;
   const long cbase = (((long)slot * p.n_kv_heads + h) * p.cache_len + j_lo) * 64;
-  float4 kv[UN], vv[UN], qv[G];
+  float4 kv[UN], vv[UN];
 #pragma unroll
   for (int u = 0; u < UN; ++u) {
     const int j = u * 4 + kk;
@@ -659,46 +662,40 @@ __global__ __launch_bounds__(256) void attn_short_kernel(AttnDev p, int n_pairs)
     kv[u] = v ? load_kv4<false>(p.kc, cbase + (long)j * 64 + dl * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     vv[u] = v ? load_kv4<false>(p.vc, cbase + (long)j * 64 + dl * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  const float4 t = *reinterpret_cast<const float4*>(p.q + (long)row * HD + hq * 64 + dl * 4);
+  const float4 qv = make_float4(t.x * 0.125f, t.y * 0.125f, t.z * 0.125f, t.w * 0.125f);
+  float s[UN];
+  float mx = -INFINITY;
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const float4 t = *reinterpret_cast<const float4*>(p.q + (long)row * HD + (h * G + g) * 64 + dl * 4);
-    qv[g] = make_float4(t.x * 0.125f, t.y * 0.125f, t.z * 0.125f, t.w * 0.125f);
+  for (int u = 0; u < UN; ++u) {
+    float d = qv.x * kv[u].x;
+    d = fmaf(qv.y, kv[u].y, d);
+    d = fmaf(qv.z, kv[u].z, d);
+    d = fmaf(qv.w, kv[u].w, d);
+    d = row16_sum(d);
+    s[u] = d;
+    if (u * 4 + kk < L) mx = fmaxf(mx, d);
   }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float den = 0.f;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
-    float s[UN];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      float t = qv[g].x * kv[u].x;
-      t = fmaf(qv[g].y, kv[u].y, t);
-      t = fmaf(qv[g].z, kv[u].z, t);
-      t = fmaf(qv[g].w, kv[u].w, t);
-      t = row16_sum(t);
-      s[u] = t;
-      if (u * 4 + kk < L) mx = fmaxf(mx, t);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float den = 0.f;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const float e = (u * 4 + kk < L) ? __expf(s[u] - mx) : 0.f;
-      den += e;
-      a.x = fmaf(e, vv[u].x, a.x); a.y = fmaf(e, vv[u].y, a.y); a.z = fmaf(e, vv[u].z, a.z); a.w = fmaf(e, vv[u].w, a.w);
-    }
-    den += __shfl_xor(den, 16);
-    den += __shfl_xor(den, 32);
-    a.x += __shfl_xor(a.x, 16); a.y += __shfl_xor(a.y, 16); a.z += __shfl_xor(a.z, 16); a.w += __shfl_xor(a.w, 16);
-    a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
-    if (kk == 0) {
-      const float inv = L > 0 ? 1.0f / den : 0.f;
-      const int k = (h * G + g) * 64 + dl * 4;
-      const float ox = __fmul_rn(a.x, inv), oy = __fmul_rn(a.y, inv), oz = __fmul_rn(a.z, inv), ow = __fmul_rn(a.w, inv);
-      if (p.out) *reinterpret_cast<float4*>(p.out + (long)row * HD + k) = make_float4(ox, oy, oz, ow);
-      if (p.out_x3) x3_emit4(p.out_x3, row, k, HD >> 5, ox, oy, oz, ow);
-    }
+  for (int u = 0; u < UN; ++u) {
+    const float e = (u * 4 + kk < L) ? __expf(s[u] - mx) : 0.f;
+    den += e;
+    a.x = fmaf(e, vv[u].x, a.x); a.y = fmaf(e, vv[u].y, a.y); a.z = fmaf(e, vv[u].z, a.z); a.w = fmaf(e, vv[u].w, a.w);
+  }
+  den += __shfl_xor(den, 16);
+  den += __shfl_xor(den, 32);
+  a.x += __shfl_xor(a.x, 16); a.y += __shfl_xor(a.y, 16); a.z += __shfl_xor(a.z, 16); a.w += __shfl_xor(a.w, 16);
+  a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
+  if (kk == 0) {
+    const float inv = L > 0 ? 1.0f / den : 0.f;
+    const int k = hq * 64 + dl * 4;
+    const float ox = __fmul_rn(a.x, inv), oy = __fmul_rn(a.y, inv), oz = __fmul_rn(a.z, inv), ow = __fmul_rn(a.w, inv);
+    if (p.out) *reinterpret_cast<float4*>(p.out + (long)row * HD + k) = make_float4(ox, oy, oz, ow);
+    if (p.out_x3) x3_emit4(p.out_x3, row, k, HD >> 5, ox, oy, oz, ow);
   }
 }
 
@@ -724,7 +721,7 @@ int launch_attention(const float* q, const void* kc, const void* vc, const int32
              d.score_cap, G);
   ST_REQUIRE(n_kv_heads <= 65535, SMOLTTS_E_INVALID, "attention: grid too large");
   if (cache_len <= 16) {
-    const int n_pairs = n_rows * n_kv_heads;
+    const int n_pairs = n_rows * n_q_heads;  // one wave per (row, query head)
     const dim3 sgrid((n_pairs + 3) / 4);
 #define ST_SHORT(GG)                                                                                       \
   case GG:                                                                                                 \
