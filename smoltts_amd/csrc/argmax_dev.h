@@ -150,13 +150,31 @@ struct QkvGather {
   int n_q_heads, n_kv_heads, cache_len, pos;
 };
 
-__device__ __forceinline__ void qkv_gather_row(const QkvGather& g, long erow, int r) {
+// The row's q | k | v: loaded by `qkv_gather_load` (up to QG_MAX float4 per thread, all requested at once, together with the RoPE
+// rows they need -- a loop over the row would be one dependent L2 round trip per iteration), finished by `qkv_gather_store`.
+constexpr int QG_MAX = 2;  // 256 threads x 2 x 4 floats = rows of up to 2048 values (150m: 1280); longer rows take more rounds
+struct QkvRegs { float4 v[QG_MAX], cs[QG_MAX]; };
+
+__device__ __forceinline__ void qkv_gather_load(const QkvGather& g, long erow, int base, QkvRegs& o) {
   const int qd = g.n_q_heads * 64, kd = g.n_kv_heads * 64, nqkv = qd + 2 * kd;
   const float* trow = g.table + erow * nqkv;
-  for (int n0 = threadIdx.x * 4; n0 < nqkv; n0 += blockDim.x * 4) {
-    float4 v = *reinterpret_cast<const float4*>(trow + n0);
+#pragma unroll
+  for (int i = 0; i < QG_MAX; ++i) {
+    const int n0 = base + (threadIdx.x + i * 256) * 4;
+    o.v[i] = n0 < nqkv ? *reinterpret_cast<const float4*>(trow + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    o.cs[i] = n0 < qd + kd ? *reinterpret_cast<const float4*>(g.rope + ((long)g.pos * 32 + ((n0 & 63) >> 1)) * 2) : make_float4(1.f, 0.f, 1.f, 0.f);
+  }
+}
+
+__device__ __forceinline__ void qkv_gather_store(const QkvGather& g, int r, int base, const QkvRegs& in) {
+  const int qd = g.n_q_heads * 64, kd = g.n_kv_heads * 64, nqkv = qd + 2 * kd;
+#pragma unroll
+  for (int i = 0; i < QG_MAX; ++i) {
+    const int n0 = base + (threadIdx.x + i * 256) * 4;
+    if (n0 >= nqkv) continue;
+    float4 v = in.v[i];
     if (n0 < qd + kd) {
-      const float4 cs = *reinterpret_cast<const float4*>(g.rope + ((long)g.pos * 32 + ((n0 & 63) >> 1)) * 2);
+      const float4 cs = in.cs[i];
       const float o0 = v.x * cs.x - v.y * cs.y, o1 = v.y * cs.x + v.x * cs.y;
       const float o2 = v.z * cs.z - v.w * cs.w, o3 = v.w * cs.z + v.z * cs.w;
       v = make_float4(o0, o1, o2, o3);
@@ -165,9 +183,9 @@ __device__ __forceinline__ void qkv_gather_row(const QkvGather& g, long erow, in
       *reinterpret_cast<float4*>(g.q_out + (long)r * qd + n0) = v;
     } else {
       const int nn = n0 - qd;
-      float* base = nn < kd ? g.kc : g.vc;
+      float* dst = nn < kd ? g.kc : g.vc;
       const int h = (nn < kd ? nn : nn - kd) >> 6, d = nn & 63;
-      *reinterpret_cast<float4*>(base + (((long)r * g.n_kv_heads + h) * g.cache_len + g.pos) * 64 + d) = v;
+      *reinterpret_cast<float4*>(dst + (((long)r * g.n_kv_heads + h) * g.cache_len + g.pos) * 64 + d) = v;
     }
   }
 }

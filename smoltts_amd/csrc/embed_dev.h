@@ -26,11 +26,21 @@ __device__ __forceinline__ void embed_row(const EmbedTables& t, const int* c, in
     const uint2 tv = *reinterpret_cast<const uint2*>(t.text_emb + (long)tok * dim + d);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (keep) {
-      for (int k = 0; k < t.n_code_rows; ++k) {  // same summation order as vq_embeds.sum(dim=1)
-        long row = (long)c[1 + k] + t.cb_first_offset + (long)k * t.codebook_size;
-        row = row < 0 ? 0 : (row >= t.cb_rows ? t.cb_rows - 1 : row);
-        const uint2 e = *reinterpret_cast<const uint2*>(t.cb_emb + row * dim + d);
-        acc.x += bf16_lo(e.x); acc.y += bf16_hi(e.x); acc.z += bf16_lo(e.y); acc.w += bf16_hi(e.y);
+      // the code rows in batches of 8, all of a batch requested before the first add (a loop of load-then-add is one L2
+      // round trip per codebook); added in codebook order: the summation order of vq_embeds.sum(dim=1)
+      for (int k0 = 0; k0 < t.n_code_rows; k0 += 8) {
+        uint2 e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = k0 + j;
+          long row = (long)c[1 + (k < t.n_code_rows ? k : 0)] + t.cb_first_offset + (long)k * t.codebook_size;
+          row = row < 0 ? 0 : (row >= t.cb_rows ? t.cb_rows - 1 : row);
+          e[j] = k < t.n_code_rows ? *reinterpret_cast<const uint2*>(t.cb_emb + row * dim + d) : make_uint2(0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (k0 + j < t.n_code_rows) { acc.x += bf16_lo(e[j].x); acc.y += bf16_hi(e[j].x); acc.z += bf16_lo(e[j].y); acc.w += bf16_hi(e[j].y); }
+        }
       }
     }
     const float4 o = make_float4(bf16_lo(tv.x) + acc.x, bf16_hi(tv.x) + acc.y, bf16_lo(tv.y) + acc.z, bf16_hi(tv.y) + acc.w);

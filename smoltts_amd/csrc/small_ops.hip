@@ -46,14 +46,28 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int n_
   if (tid == 0) ids[(long)r * ids_stride] = id;
   if (emb == nullptr) return;
   const long erow = (long)id + emb_row_offset;
-  if (qg.table) qkv_gather_row(qg, erow, r);
+  // everything that depends on the id is requested in one go: the embedding row and (where the engine has the table) the row's
+  // layer-0 q | k | v with their RoPE rows -- one memory round trip behind the pick instead of one per loop iteration
+  const int d0 = tid * 4;
+  uint2 e0 = make_uint2(0, 0);
+  if (d0 < dim) e0 = *reinterpret_cast<const uint2*>(emb + erow * dim + d0);
+  QkvRegs qr;
+  const int nqkv = qg.table ? (qg.n_q_heads + 2 * qg.n_kv_heads) * 64 : 0;
+  if (qg.table) qkv_gather_load(qg, erow, 0, qr);
   float ss = 0.f;
-  for (int d = tid * 4; d < dim; d += 256 * 4) {
-    const uint2 e = *reinterpret_cast<const uint2*>(emb + erow * dim + d);
+  for (int d = d0; d < dim; d += 256 * 4) {
+    const uint2 e = d == d0 ? e0 : *reinterpret_cast<const uint2*>(emb + erow * dim + d);
     const float4 o = make_float4(bf16_lo(e.x), bf16_hi(e.x), bf16_lo(e.y), bf16_hi(e.y));
     *reinterpret_cast<float4*>(xnext + (long)r * dim + d) = o;
     ss += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
     emit_x4(emit, r, d, dim >> 5, o.x, o.y, o.z, o.w);
+  }
+  if (qg.table) {
+    qkv_gather_store(qg, r, 0, qr);
+    for (int base = QG_MAX * 1024; base < nqkv; base += QG_MAX * 1024) {  // (rows beyond 2048 values: further rounds)
+      qkv_gather_load(qg, erow, base, qr);
+      qkv_gather_store(qg, r, base, qr);
+    }
   }
   emit_row_ssq(emit, r, dim, ss, sh4);
 }
