@@ -37,7 +37,7 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("TORCH_COMPILE_DISABLE", "1")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-PROFILE_TAG = "r02"    # profiles/<tag>_* hold the rocprofv3 summaries of this round
+PROFILE_TAG = "r03"    # profiles/<tag>_* hold the rocprofv3 summaries of this round
 
 _T0 = time.perf_counter()
 

@@ -520,7 +520,11 @@ class BatchScheduler:
     def _run(self) -> None:
         torch = self._torch
         try:
-            compute = torch.cuda.Stream()
+            # the ticks are a chain of ~200 dependent launches per frame: their queue goes first wherever the command processor
+            # has a choice (the codec passes beside them are ~100 launches per pass; measured with a kernel trace of
+            # tools/bench_scheduler.py: no LM kernel gets longer beside a codec pass, the chain only loses time BETWEEN its kernels)
+            prio = int(__import__("os").environ.get("SMOLTTS_TICK_PRIORITY", "-1"))
+            compute = torch.cuda.Stream(priority=prio)
             self._copy_stream = torch.cuda.Stream()
             self._codec_stream = torch.cuda.Stream()
             with torch.cuda.stream(compute):

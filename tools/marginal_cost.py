@@ -46,7 +46,8 @@ def timed(n=8):
 base = timed()
 print(f"frame graph: {base:.1f} us")
 L, F, S = cfg.n_layer, cfg.n_fast_layer, cfg.max_fast_seqlen
-cases = [("wqkv GEMM + RoPE + cache (N=1280)", 5, (cfg.n_head + 2 * cfg.n_local_heads) * 64, L + F * S),
+wqkv_launches = L + F * S - ((S - 1) if eng.fast_qkv is not None else 0)  # the table replaces depth layer 0's wqkv in steps 1..S-1
+cases = [("wqkv GEMM + RoPE + cache (N=1280)", 5, (cfg.n_head + 2 * cfg.n_local_heads) * 64, wqkv_launches),
          ("w1|w3 GEMM + SwiGLU", 2, 2 * cfg.intermediate_size, L + F * S),
          ("slow head GEMM (N=2368)", 0, cfg.vocab_size, 1),
          ("depth head GEMM (N=2048)", 0, cfg.codebook_size, S),
