@@ -212,6 +212,16 @@ int smoltts_session_set_frames_per_graph(SmolttsSession* s, int32_t n, void* str
 #define SMOLTTS_OPT_QKV_TABLE 1
 #define SMOLTTS_OPT_COMMIT_PICKS 2
 #define SMOLTTS_OPT_SPLIT_ATTN 3
+#define SMOLTTS_OPT_STREAM_W 4  /* value = mask of SMOLTTS_STREAM_W_*: which weights of a decode frame are loaded with the non-temporal
+                                  hint (read once per frame: keeping them out of the caches leaves room for the depth layers'
+                                  weights, which are re-read for each of the 8 depth steps) */
+#define SMOLTTS_STREAM_W_SLOW 1        /* the slow transformer's blocks */
+#define SMOLTTS_STREAM_W_SLOW_HEAD 2   /* the slow head */
+#define SMOLTTS_STREAM_W_DEPTH_HEAD 4  /* the depth head slices (one per step) */
+#define SMOLTTS_STREAM_W_DEPTH_W13 8   /* experiments: parts of the depth blocks */
+#define SMOLTTS_STREAM_W_DEPTH_W2 16
+#define SMOLTTS_STREAM_W_DEPTH_QKVO 32
+#define SMOLTTS_STREAM_W_DEFAULT (SMOLTTS_STREAM_W_SLOW | SMOLTTS_STREAM_W_SLOW_HEAD)
 int smoltts_session_set_option(SmolttsSession* s, int32_t option, int32_t value);
 
 /* Sampling mode (reference GenerationSettings, lm/generate.py:12-16): temp / fast_temp <= 0 select
@@ -440,6 +450,9 @@ typedef struct SmolttsGemm3Args {
                                   the output projection (each kv head repeated for its query heads) and no attention
                                   launch is needed */
   int32_t kv_format;           /* EPI_QKV_ROPE: SMOLTTS_KV_F32 | SMOLTTS_KV_BF16 storage of k_cache_dev / v_cache_dev */
+  int32_t w_stream;            /* != 0: these weights are read once now and not again before the caches have turned over (the slow
+                                  layers of a decode frame): their loads carry the non-temporal hint, so that they do not push the
+                                  depth transformer's weights -- re-read 8 times per frame -- out of the Infinity Cache (M <= 128 only) */
 } SmolttsGemm3Args;
 
 int smoltts_k_gemm3(const SmolttsGemm3Args* a, void* stream);

@@ -33,6 +33,30 @@ struct AttnDev {
   int* split_ticket;   // [pairs] arrival tickets, counting up across launches (NS arrivals per pair and launch)
 };
 
+// The slow cache is read once per frame and is far larger than anything that could stay cached: with SMOLTTS_NT_KV its loads
+// carry the non-temporal hint, so that a frame's 100-400 MB of K / V rows do not sweep the weights out of the Infinity Cache.
+#ifndef SMOLTTS_NT_KV
+#define SMOLTTS_NT_KV 0
+#endif
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_f4_stream(const float* p) {
+#if SMOLTTS_NT_KV
+  const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+#else
+  return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ uint4 ld_u4_stream(const uint16_t* p) {
+#if SMOLTTS_NT_KV
+  const u32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+#else
+  return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+
 // 4 consecutive cache elements starting at element index e: fp32 (16 B) or bf16 (8 B, widened exactly)
 template <bool KB>
 __device__ __forceinline__ float4 load_kv4(const void* base, long e) {
@@ -213,11 +237,11 @@ template <bool KB> struct KVLane { static constexpr int LPK = KB ? 8 : 16, DPL =
 template <bool KB>
 __device__ __forceinline__ void load_kv_lane(const void* base, long e, bool ok, KVLane<KB>& o) {
   if constexpr (KB) {  // 8 bf16 elements, widened exactly
-    const uint4 t = ok ? *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(base) + e) : make_uint4(0, 0, 0, 0);
+    const uint4 t = ok ? ld_u4_stream(static_cast<const uint16_t*>(base) + e) : make_uint4(0, 0, 0, 0);
     o.v[0] = bf16_lo(t.x); o.v[1] = bf16_hi(t.x); o.v[2] = bf16_lo(t.y); o.v[3] = bf16_hi(t.y);
     o.v[4] = bf16_lo(t.z); o.v[5] = bf16_hi(t.z); o.v[6] = bf16_lo(t.w); o.v[7] = bf16_hi(t.w);
   } else {
-    const float4 t = ok ? *reinterpret_cast<const float4*>(static_cast<const float*>(base) + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 t = ok ? ld_f4_stream(static_cast<const float*>(base) + e) : make_float4(0.f, 0.f, 0.f, 0.f);
     o.v[0] = t.x; o.v[1] = t.y; o.v[2] = t.z; o.v[3] = t.w;
   }
 }
@@ -283,8 +307,8 @@ __global__ __launch_bounds__(1024) void attn_split_kernel(AttnDev p) {
       for (int u = 0; u < UNB; ++u) {
         const int j = j0 + u * step;
         const bool ok = j < L;
-        kr[u] = ok ? *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.kc) + ebase + (long)j * 64) : make_uint4(0, 0, 0, 0);
-        vr[u] = ok ? *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.vc) + ebase + (long)j * 64) : make_uint4(0, 0, 0, 0);
+        kr[u] = ok ? ld_u4_stream(static_cast<const uint16_t*>(p.kc) + ebase + (long)j * 64) : make_uint4(0, 0, 0, 0);
+        vr[u] = ok ? ld_u4_stream(static_cast<const uint16_t*>(p.vc) + ebase + (long)j * 64) : make_uint4(0, 0, 0, 0);
       }
       float sc[G][UNB];
 #pragma unroll

@@ -37,6 +37,7 @@ struct Gemm3Dev {
   const float* wscale;  // fp8 weights: per-output-row scale [N]; nullptr = bf16 weights
   const char* x3;
   int M, N, K;
+  int w_nt;       // weight loads carry the non-temporal hint (SmolttsGemm3Args.w_stream)
   int half_rows;  // MT == 1 only: a workgroup owns 8 of the tile's 16 rows (twice the workgroups, half the X3 bytes each)
   const float* ssq_in;
   float eps;
@@ -72,13 +73,14 @@ struct Gemm3Dev {
 // Weight tiles are read once per launch by the one or two workgroups that own them: with
 // SMOLTTS_NT_W the loads carry the non-temporal hint (MI355X_MICROARCH.md 'nt-weights').
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+template <bool NT>
 __device__ __forceinline__ uint4 load_w16(const char* ptr) {
-#if defined(SMOLTTS_NT_W) && SMOLTTS_NT_W
-  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(ptr));
-  return make_uint4(v[0], v[1], v[2], v[3]);
-#else
+  if (NT) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(ptr));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+  }
   return *reinterpret_cast<const uint4*>(ptr);
-#endif
 }
 
 // fp8 weights (e4m3, per-row scale applied in the epilogue): a lane's 8 bytes -> the bf16x8 A fragment.
@@ -95,13 +97,17 @@ __device__ __forceinline__ bf16x8_t fp8x8_to_bf16x8(uint32_t lo, uint32_t hi) {
   o.w = bf16_pair(__builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true));
   return __builtin_bit_cast(bf16x8_t, o);
 }
-template <bool W8>
+template <bool W8, bool NT = false>
 __device__ __forceinline__ uint4 load_wfrag(const char* ptr) {  // ptr already includes the lane offset
   if (W8) {
+    if (NT) {
+      const u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(ptr));
+      return make_uint4(v[0], v[1], 0, 0);
+    }
     const uint2 v = *reinterpret_cast<const uint2*>(ptr);
     return make_uint4(v.x, v.y, 0, 0);
   }
-  return load_w16(ptr);
+  return load_w16<NT>(ptr);
 }
 template <bool W8>
 __device__ __forceinline__ bf16x8_t wfrag_bf16(uint4 v) {
@@ -110,7 +116,7 @@ __device__ __forceinline__ bf16x8_t wfrag_bf16(uint4 v) {
 
 __device__ __forceinline__ float silu3(float x) { return x / (1.f + expf(-x)); }
 
-template <int MT, int T, int U, int EPI, bool W8>
+template <int MT, int T, int U, int EPI, bool W8, bool NT = false>  // NT: weight loads with the non-temporal hint (Gemm3Dev.w_nt)
 __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
   constexpr int WTILE = W8 ? 512 : 1024, WLANE = W8 ? 8 : 16;  // bytes per weight tile-chunk / per lane
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
       const bool cv = c < nchunks;
 #pragma unroll
       for (int t = 0; t < T; ++t)
-        wf[u][t] = (cv && wv[t]) ? load_wfrag<W8>(wb[t] + (size_t)c * WTILE) : make_uint4(0, 0, 0, 0);
+        wf[u][t] = (cv && wv[t]) ? load_wfrag<W8, NT>(wb[t] + (size_t)c * WTILE) : make_uint4(0, 0, 0, 0);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -505,7 +511,8 @@ static int launch3_one(const Gemm3Dev& d, int nwaves, hipStream_t stream) {
   if (nwaves < MT * T) nwaves = MT * T;  // one finishing wave per (column tile, row tile) of the workgroup
   const dim3 grid((ntiles + T - 1) / T, ((d.M + 16 * MT - 1) / (16 * MT)) * (d.half_rows ? 2 : 1));
   const size_t lds = (size_t)nwaves * T * MT * 1024 + (size_t)MT * 16 * sizeof(float);  // partial tiles + the row scales
-  hipLaunchKernelGGL((gemm3_kernel<MT, T, U, EPI, W8>), grid, dim3(nwaves * 64), lds, stream, d);
+  if (MT == 1 && d.w_nt) hipLaunchKernelGGL((gemm3_kernel<MT, T, U, EPI, W8, MT == 1>), grid, dim3(nwaves * 64), lds, stream, d);
+  else hipLaunchKernelGGL((gemm3_kernel<MT, T, U, EPI, W8>), grid, dim3(nwaves * 64), lds, stream, d);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
 }
@@ -581,6 +588,7 @@ static int launch_gemm3_impl(const SmolttsGemm3Args& a, hipStream_t stream) {
   d.rope = a.rope_dev; d.row_pos = a.row_pos_dev; d.row_slot = a.row_slot_dev; d.kc = a.k_cache_dev; d.vc = a.v_cache_dev;
   d.n_q_heads = a.n_q_heads; d.n_kv_heads = a.n_kv_heads; d.cache_len = a.cache_len;
   d.kv_bf16 = a.kv_format == SMOLTTS_KV_BF16;
+  d.w_nt = a.w_stream != 0;
   d.v_x3 = a.epilogue == SMOLTTS_EPI_QKV_ROPE ? (char*)a.v_x3_dev : nullptr;
 #ifdef SMOLTTS_DEBUG_HOOKS
   d.stamps = debug_stamp_buffer();

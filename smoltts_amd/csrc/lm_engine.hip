@@ -90,6 +90,7 @@ struct SmolttsSession {
   bool use_qkv_table;          // depth layer-0 q | k | v from the engine's table where it exists (SMOLTTS_OPT_QKV_TABLE)
   bool commit_picks;           // slow token and last depth code picked inside the commit kernel (SMOLTTS_OPT_COMMIT_PICKS)
   bool split_attn;             // slow attention of few rows over two workgroups per (row, kv head) (SMOLTTS_OPT_SPLIT_ATTN)
+  int stream_w;                // which weights of a decode frame are loaded with the non-temporal hint (SMOLTTS_OPT_STREAM_W, bit mask)
 };
 
 namespace {
@@ -295,7 +296,8 @@ int launch_gemm3_m(const SmolttsSession* s, const SmolttsGemm3Args& a, hipStream
 int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, int n_head, int n_kv, int inter, float* x,
               float* q, int M, const int* row_pos, const int* row_slot, const float* rope, void* kc, void* vc,
               int cache_len, const char* in_x3, const EmitArgs& next, hipStream_t st, bool first_pos = false,
-              int kv_format = SMOLTTS_KV_F32, int iota_pos = -1, bool qkv_done = false) {
+              int kv_format = SMOLTTS_KV_F32, int iota_pos = -1, bool qkv_done = false, int w_stream = 0) {
+  // w_stream: 1 = every matrix of the block, or a mask of SMOLTTS_STREAM_W_DEPTH_* bits (which of a depth block's matrices)
   // qkv_done: q and the cache rows of this block are in place already (gathered from the engine's fast_qkv table by the
   // kernel that picked the row's code): no wqkv launch
   // iota_pos >= 0: row r is slot r at that position (the depth steps): the attention kernel needs no row_pos / row_slot loads
@@ -309,7 +311,7 @@ int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, i
     a.ssq_in_dev = s->ssq; a.eps = eps; a.out_dev = q; a.ldo = n_head * 64;
     a.rope_dev = rope; a.row_pos_dev = row_pos; a.row_slot_dev = row_slot;
     a.k_cache_dev = (float*)kc; a.v_cache_dev = (float*)vc; a.n_q_heads = n_head; a.n_kv_heads = n_kv; a.cache_len = cache_len;
-    a.kv_format = kv_format;
+    a.kv_format = kv_format; a.w_stream = (w_stream & (1 | SMOLTTS_STREAM_W_DEPTH_QKVO)) != 0;
     if (first_pos) a.v_x3_dev = s->x3a;
     ST_TRY(launch_gemm3_m(s, a, st));
   }
@@ -322,19 +324,19 @@ int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, i
   {  // x += attn . Wo^T ; publish x * ffn_norm for w1|w3
     SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.wo, s->x3a, M, dim, dim, SMOLTTS_EPI_RESID);
     a.resid_dev = x; a.out_dev = x; a.ldo = dim;
-    a.emit_a_dev = s->x3n; a.gamma_a_dev = (const float*)(A + bw.ffn_norm); a.ssq_out_dev = s->ssq;
+    a.emit_a_dev = s->x3n; a.gamma_a_dev = (const float*)(A + bw.ffn_norm); a.ssq_out_dev = s->ssq; a.w_stream = (w_stream & (1 | SMOLTTS_STREAM_W_DEPTH_QKVO)) != 0;
     ST_TRY(launch_gemm3(a, st));
   }
   {  // h = silu(w1 n) * (w3 n), n = RMSNorm(x); written as w2's operand
     SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.w13, s->x3n, M, 2 * inter, dim, SMOLTTS_EPI_SWIGLU);
-    a.ssq_in_dev = s->ssq; a.eps = eps; a.x3_out_dev = s->x3h;
+    a.ssq_in_dev = s->ssq; a.eps = eps; a.x3_out_dev = s->x3h; a.w_stream = (w_stream & (1 | SMOLTTS_STREAM_W_DEPTH_W13)) != 0;
     ST_TRY(launch_gemm3_m(s, a, st));
   }
   {  // x += h . W2^T ; publish for the next consumer(s)
     SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.w2, s->x3h, M, dim, inter, SMOLTTS_EPI_RESID);
     a.resid_dev = x; a.out_dev = x; a.ldo = dim;
     a.emit_a_dev = next.x3a; a.gamma_a_dev = next.gamma_a; a.emit_b_dev = next.x3b; a.gamma_b_dev = next.gamma_b;
-    a.ssq_out_dev = next.ssq;
+    a.ssq_out_dev = next.ssq; a.w_stream = (w_stream & (1 | SMOLTTS_STREAM_W_DEPTH_W2)) != 0;
     ST_TRY(launch_gemm3(a, st));
   }
   return SMOLTTS_OK;
@@ -401,7 +403,7 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
   const int B = s->B, H = 1 + c.n_fast;
   {  // logits = RMSNorm(x) . E^T   (lm/rq_transformer.py:184-189); the token is picked by the commit kernel: nothing before it needs it
     SmolttsGemm3Args a = base3(c.weight_format, A + e->w.head, s->x3n, B, c.vocab_size, c.dim, SMOLTTS_EPI_STORE);
-    a.ssq_in_dev = s->ssq; a.eps = c.norm_eps; a.out_dev = s->logits_slow; a.ldo = c.vocab_size;
+    a.ssq_in_dev = s->ssq; a.eps = c.norm_eps; a.out_dev = s->logits_slow; a.ldo = c.vocab_size; a.w_stream = (s->stream_w & SMOLTTS_STREAM_W_SLOW_HEAD) != 0;
     ST_TRY(launch_gemm3_m(s, a, st));
   }
   const bool picks = s->commit_picks;
@@ -431,13 +433,15 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
       ST_TRY(run_block(s, e->w.fast_layers[l], c.fast_dim, c.fast_n_head, c.fast_n_kv_head, c.fast_inter, xf, s->qt, B,
                        s->fastpos + (size_t)i * B, s->iota, (const float*)(A + e->w.fast_rope), s->fkc + l * fl_stride,
                        s->fvc + l * fl_stride, c.n_fast, (i == 0 && l == 0) ? first_x3 : s->x3n, next, st, /*first_pos=*/i == 0,
-                       SMOLTTS_KV_F32, /*iota_pos=*/i, /*qkv_done=*/table && i > 0 && l == 0));
+                       SMOLTTS_KV_F32, /*iota_pos=*/i, /*qkv_done=*/table && i > 0 && l == 0,
+                       /*w_stream=*/s->stream_w & (SMOLTTS_STREAM_W_DEPTH_QKVO | SMOLTTS_STREAM_W_DEPTH_W13 | SMOLTTS_STREAM_W_DEPTH_W2)));
     }
     {  // fast_norm + depthwise head slice i  (lm/rq_transformer.py:209-217)
       const size_t wrow = (size_t)i * e->w.fast_head_step_stride;  // rows; a row tile is 16 rows
       const size_t wbytes = c.weight_format == SMOLTTS_W_FP8 ? wrow * (c.fast_dim + 4) : wrow * c.fast_dim * 2;
       SmolttsGemm3Args a = base3(c.weight_format, A + e->w.fast_head + wbytes, s->x3n, B, c.codebook_size, c.fast_dim, SMOLTTS_EPI_STORE);
       a.ssq_in_dev = s->ssq; a.eps = c.norm_eps; a.out_dev = s->logits; a.ldo = c.codebook_size;
+      a.w_stream = (s->stream_w & SMOLTTS_STREAM_W_DEPTH_HEAD) != 0;  // each head slice is read once per frame
       ST_TRY(launch_gemm3_m(s, a, st));
     }
     const SampleArgs fast_sa{s->fast_temp, s->fast_temp > 0.f ? s->min_p : 0.f, s->seed, 1 + i, 0, s->frames, s->salt, s->margin_at};
@@ -475,7 +479,7 @@ int run_slow_layers(SmolttsSession* s, float* x, float* q, int M, const int* row
     else if (publish_hidden) next = slow_hidden_emit(s);
     ST_TRY(run_block(s, e->w.layers[l], c.dim, c.n_head, c.n_kv_head, c.inter, x, q, M, row_pos, row_slot,
                      (const float*)(e->arena + e->w.rope), s->kc + l * l_stride, s->vc + l * l_stride, s->max_seq, s->x3n, next, st,
-                     /*first_pos=*/false, s->kv_format));
+                     /*first_pos=*/false, s->kv_format, -1, false, /*w_stream=*/((s->stream_w & SMOLTTS_STREAM_W_SLOW) && M <= 128) ? 1 : 0));
   }
   return SMOLTTS_OK;
 }
@@ -729,6 +733,7 @@ int smoltts_session_create_kv(SmolttsEngine* e, void* slab_dev, size_t slab_byte
   s->use_qkv_table = true;
   s->commit_picks = true;
   s->split_attn = true;
+  s->stream_w = SMOLTTS_STREAM_W_DEFAULT;
   s->kv_format = kv_format;
   size_t total = 0;
   carve(s, (char*)slab_dev, &total);
@@ -958,6 +963,7 @@ int smoltts_session_set_option(SmolttsSession* s, int32_t option, int32_t value)
     case SMOLTTS_OPT_QKV_TABLE: s->use_qkv_table = value != 0; break;
     case SMOLTTS_OPT_COMMIT_PICKS: s->commit_picks = value != 0; break;
     case SMOLTTS_OPT_SPLIT_ATTN: s->split_attn = value != 0; break;
+    case SMOLTTS_OPT_STREAM_W: s->stream_w = value; break;
     default:
       set_error("session_set_option: unknown option %d", option);
       return SMOLTTS_E_INVALID;

@@ -291,7 +291,7 @@ def _fill_block(dst: BlockWeights, src: Dict[str, int]) -> None:
         setattr(dst, k, v)
 
 
-OPT_QKV_TABLE, OPT_COMMIT_PICKS, OPT_SPLIT_ATTN = 1, 2, 3  # include/smoltts_hip.h SMOLTTS_OPT_*
+OPT_QKV_TABLE, OPT_COMMIT_PICKS, OPT_SPLIT_ATTN, OPT_STREAM_W = 1, 2, 3, 4  # include/smoltts_hip.h SMOLTTS_OPT_*
 
 
 class LMEngine:
@@ -402,6 +402,8 @@ class LMSession:
             self.use_commit_picks(False)
         if os.environ.get("SMOLTTS_SPLIT_ATTN") == "0":
             self.use_split_attention(False)
+        if os.environ.get("SMOLTTS_STREAM_W") is not None:  # mask of SMOLTTS_STREAM_W_* bits
+            check(self.lib.smoltts_session_set_option(self.handle, OPT_STREAM_W, int(os.environ["SMOLTTS_STREAM_W"])), "smoltts_session_set_option")
 
     def prefill(self, prompts: Sequence[np.ndarray], slots: Optional[Sequence[int]] = None, stop_on_eos: bool = True,
                 pos0: Optional[Sequence[int]] = None, final: bool = True, defer_frame0: bool = False) -> None:

@@ -169,6 +169,7 @@ class Gemm3Args(C.Structure):
         ("k_cache_dev", C.c_void_p), ("v_cache_dev", C.c_void_p), ("n_q_heads", C.c_int32), ("n_kv_heads", C.c_int32),
         ("cache_len", C.c_int32), ("w_format", C.c_int32), ("w_scale_dev", C.c_void_p), ("v_x3_dev", C.c_void_p),
         ("kv_format", C.c_int32),
+        ("w_stream", C.c_int32),
     ]
 
 
@@ -187,7 +188,7 @@ def linear3(x3: torch.Tensor, w_tiles: torch.Tensor, M: int, N: int, K: int, *, 
             emit_b: Optional[torch.Tensor] = None, gamma_b: Optional[torch.Tensor] = None,
             ssq_out: Optional[torch.Tensor] = None, rope=None, row_pos=None, row_slot=None, k_cache=None, v_cache=None,
             n_q_heads: int = 0, n_kv_heads: int = 0, cache_len: int = 0, w_scale: Optional[torch.Tensor] = None,
-            v_x3: Optional[torch.Tensor] = None, kv_format: int = 0):
+            v_x3: Optional[torch.Tensor] = None, kv_format: int = 0, w_stream: bool = False):
     """The bf16-MFMA GEMM over an X3 operand; returns the fp32 ``out`` tensor (None for SWIGLU).
     ``w_scale`` given: ``w_tiles`` are e4m3 tiles (``pack_weight_fp8``)."""
     lib = E.load_library()
@@ -209,5 +210,6 @@ def linear3(x3: torch.Tensor, w_tiles: torch.Tensor, M: int, N: int, K: int, *, 
     a.w_format, a.w_scale_dev = (1, E.dptr(w_scale)) if w_scale is not None else (0, None)
     a.v_x3_dev = E.dptr(v_x3)
     a.kv_format = int(kv_format)
+    a.w_stream = 1 if w_stream else 0
     E.check(lib.smoltts_k_gemm3(C.byref(a), E.current_stream_ptr()), "smoltts_k_gemm3")
     return out

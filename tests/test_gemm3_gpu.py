@@ -63,6 +63,21 @@ def test_gemm3_norm_store(E, ops, M, K, N):
     assert rel_err(out.cpu(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("M,K,N", [(32, 768, 6144), (32, 3072, 768), (7, 576, 960)])
+def test_gemm3_streamed_weights_are_the_same_numbers(E, ops, M, K, N):
+    """SmolttsGemm3Args.w_stream only changes the cache policy of the weight loads (non-temporal hint): same bits out."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    w = bf16r(torch.randn(N, K, generator=g) * 0.05)
+    gamma = 1 + 0.1 * torch.randn(K, generator=g)
+    x3, _, ssq = ops.x3_pack(x.cuda(), gamma.cuda())
+    wt = ops.pack_weight(w)
+    a = ops.linear3(x3, wt, M, N, K, ssq_in=ssq)
+    b = ops.linear3(x3, wt, M, N, K, ssq_in=ssq, w_stream=True)
+    assert torch.equal(a, b)
+    assert rel_err(a.cpu(), rms_norm_ref(x, gamma, 1e-5) @ w.T) < 2e-5
+
+
 @pytest.mark.parametrize("M,K,N", [(32, 3072, 768), (5, 1536, 576), (40, 768, 768)])
 def test_gemm3_resid_emit(E, ops, M, K, N):
     g = torch.Generator().manual_seed(M + K)
