@@ -221,7 +221,11 @@ int smoltts_session_set_frames_per_graph(SmolttsSession* s, int32_t n, void* str
 #define SMOLTTS_STREAM_W_DEPTH_W13 8   /* experiments: parts of the depth blocks */
 #define SMOLTTS_STREAM_W_DEPTH_W2 16
 #define SMOLTTS_STREAM_W_DEPTH_QKVO 32
-#define SMOLTTS_STREAM_W_DEFAULT (SMOLTTS_STREAM_W_SLOW | SMOLTTS_STREAM_W_SLOW_HEAD)
+#define SMOLTTS_STREAM_W_SLOW_ONLY_W13 64   /* with _SLOW: only the slow blocks' w1|w3 (the rest of the slow weights stays cacheable) */
+#define SMOLTTS_STREAM_W_SLOW_NOT_W13 128   /* with _SLOW: everything of the slow blocks but w1|w3 */
+/* default: the slow blocks' w1|w3 (94 MB at 150m) and the slow head stream past the caches; what is left -- the depth
+ * transformer (94 MB, re-read 8 times per frame) and the rest of the slow blocks (83 MB) -- fits the 256 MB Infinity Cache together */
+#define SMOLTTS_STREAM_W_DEFAULT (SMOLTTS_STREAM_W_SLOW | SMOLTTS_STREAM_W_SLOW_HEAD | SMOLTTS_STREAM_W_SLOW_ONLY_W13)
 int smoltts_session_set_option(SmolttsSession* s, int32_t option, int32_t value);
 
 /* Sampling mode (reference GenerationSettings, lm/generate.py:12-16): temp / fast_temp <= 0 select

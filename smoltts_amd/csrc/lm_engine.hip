@@ -479,7 +479,8 @@ int run_slow_layers(SmolttsSession* s, float* x, float* q, int M, const int* row
     else if (publish_hidden) next = slow_hidden_emit(s);
     ST_TRY(run_block(s, e->w.layers[l], c.dim, c.n_head, c.n_kv_head, c.inter, x, q, M, row_pos, row_slot,
                      (const float*)(e->arena + e->w.rope), s->kc + l * l_stride, s->vc + l * l_stride, s->max_seq, s->x3n, next, st,
-                     /*first_pos=*/false, s->kv_format, -1, false, /*w_stream=*/((s->stream_w & SMOLTTS_STREAM_W_SLOW) && M <= 128) ? 1 : 0));
+                     /*first_pos=*/false, s->kv_format, -1, false, /*w_stream=*/((s->stream_w & SMOLTTS_STREAM_W_SLOW) && M <= 128)
+                         ? ((s->stream_w & SMOLTTS_STREAM_W_SLOW_ONLY_W13) ? SMOLTTS_STREAM_W_DEPTH_W13 : ((s->stream_w & SMOLTTS_STREAM_W_SLOW_NOT_W13) ? (SMOLTTS_STREAM_W_DEPTH_W2 | SMOLTTS_STREAM_W_DEPTH_QKVO) : 1)) : 0));
   }
   return SMOLTTS_OK;
 }
