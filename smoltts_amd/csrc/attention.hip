@@ -189,16 +189,27 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
   // ---- merge the waves
   if (tid < G * 16) {
     const int g = tid >> 4, d4 = (tid & 15) * 4;
+    // every wave's (max, denominator, sums) requested from LDS at once: a loop over a run-time wave count is one LDS round trip
+    // per iteration on the critical path of a latency-bound launch (at most 16 waves; absent ones contribute nothing)
+    float wm[16], wd[16];
+    float4 wt[16];
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int ww = w < nwaves ? w : 0;
+      wm[w] = w < nwaves ? stat[(ww * G + g) * 2] : -INFINITY;
+      wd[w] = stat[(ww * G + g) * 2 + 1];
+      wt[w] = *reinterpret_cast<const float4*>(part + (ww * G + g) * 64 + d4);
+    }
     float gm = -INFINITY;
-    for (int w = 0; w < nwaves; ++w) gm = fmaxf(gm, stat[(w * G + g) * 2]);
+#pragma unroll
+    for (int w = 0; w < 16; ++w) gm = fmaxf(gm, wm[w]);
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
     float dsum = 0.f;
-    for (int w = 0; w < nwaves; ++w) {
-      const float wm = stat[(w * G + g) * 2];
-      const float sc = wm > -INFINITY ? __expf(wm - gm) : 0.f;
-      const float4 t = *reinterpret_cast<const float4*>(part + (w * G + g) * 64 + d4);
-      sum.x = fmaf(t.x, sc, sum.x); sum.y = fmaf(t.y, sc, sum.y); sum.z = fmaf(t.z, sc, sum.z); sum.w = fmaf(t.w, sc, sum.w);
-      dsum = fmaf(stat[(w * G + g) * 2 + 1], sc, dsum);
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const float sc = wm[w] > -INFINITY ? __expf(wm[w] - gm) : 0.f;
+      sum.x = fmaf(wt[w].x, sc, sum.x); sum.y = fmaf(wt[w].y, sc, sum.y); sum.z = fmaf(wt[w].z, sc, sum.z); sum.w = fmaf(wt[w].w, sc, sum.w);
+      dsum = fmaf(wd[w], sc, dsum);
     }
     const float inv = 1.0f / dsum;
     const int k = (h * G + g) * 64 + d4;
@@ -419,16 +430,26 @@ __global__ __launch_bounds__(1024) void attn_split_kernel(AttnDev p) {
   // ---- merge the waves
   const bool on = tid < G * 16;
   const int g = on ? tid >> 4 : 0, d4 = (tid & 15) * 4;
+  // (all waves' partials requested from LDS at once: see attn_kernel)
+  float wm[16], wd[16];
+  float4 wt[16];
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const int ww = w < nwaves ? w : 0;
+    wm[w] = w < nwaves ? stat[(ww * G + g) * 2] : -INFINITY;
+    wd[w] = stat[(ww * G + g) * 2 + 1];
+    wt[w] = *reinterpret_cast<const float4*>(part + (ww * G + g) * 64 + d4);
+  }
   float gm = -INFINITY;
-  for (int w = 0; w < nwaves; ++w) gm = fmaxf(gm, stat[(w * G + g) * 2]);
+#pragma unroll
+  for (int w = 0; w < 16; ++w) gm = fmaxf(gm, wm[w]);
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
   float dsum = 0.f;
-  for (int w = 0; w < nwaves; ++w) {
-    const float wm = stat[(w * G + g) * 2];
-    const float sc = wm > -INFINITY ? __expf(wm - gm) : 0.f;
-    const float4 t = *reinterpret_cast<const float4*>(part + (w * G + g) * 64 + d4);
-    sum.x = fmaf(t.x, sc, sum.x); sum.y = fmaf(t.y, sc, sum.y); sum.z = fmaf(t.z, sc, sum.z); sum.w = fmaf(t.w, sc, sum.w);
-    dsum = fmaf(stat[(w * G + g) * 2 + 1], sc, dsum);
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const float sc = wm[w] > -INFINITY ? __expf(wm[w] - gm) : 0.f;
+    sum.x = fmaf(wt[w].x, sc, sum.x); sum.y = fmaf(wt[w].y, sc, sum.y); sum.z = fmaf(wt[w].z, sc, sum.z); sum.w = fmaf(wt[w].w, sc, sum.w);
+    dsum = fmaf(wd[w], sc, dsum);
   }
   if (shared) {
     // ---- publish this part's record, take a ticket; the workgroup that completes the pair merges all parts in part order
