@@ -98,8 +98,8 @@ def parse_args(argv=None):
 
 
 # ------------------------------------------------------------------------------------------- launcher
-def self_launch(n: int, argv) -> int:
-    """Parent of an N-rank run: spawn one child per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
+def _launch_once(n: int, argv, pin: bool):
+    """One attempt of the parent of an N-rank run (-> (exit code, seconds it took, did rank 0 print its line)): spawn one child per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
     torch.distributed.run sets them), relay rank 0's stdout, return the first non-zero exit code (0 if none).  This
     process makes no GPU call (it does not even import torch).  Every child runs in a session of its own and sees exactly
     one GPU (HIP_VISIBLE_DEVICES = its entry of the parent's device list, set before the child's first GPU call;
@@ -114,11 +114,12 @@ def self_launch(n: int, argv) -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    pin = os.environ.get("SMOLTTS_BENCH_PIN_DEVICES", "1") != "0" and os.environ.get("SMOLTTS_BENCH_ONE_DEVICE") != "1"
+    t_start = time.time()
+    printed = []
     visible = [d for d in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if d.strip()] or [str(i) for i in range(n)]
     if pin and len(visible) < n:
         print(f"[bench launcher] HIP_VISIBLE_DEVICES lists {len(visible)} devices for {n} ranks", file=sys.stderr, flush=True)
-        return 2
+        return 2, 0.0, False
     procs = []
 
     def stop_children(grace=15.0):
@@ -154,7 +155,10 @@ def self_launch(n: int, argv) -> int:
 
         def relay(p):  # the result line goes to stdout; anything else a library prints there (gloo / RCCL banners) to stderr
             for line in p.stdout:
-                dst = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+                is_line = line.lstrip().startswith("{")
+                if is_line:
+                    printed.append(1)
+                dst = sys.stdout if is_line else sys.stderr
                 dst.write(line)
                 dst.flush()
 
@@ -179,6 +183,20 @@ def self_launch(n: int, argv) -> int:
             signal.signal(sig, h)
         if t is not None:
             t.join(timeout=5)
+    return rc, time.time() - t_start, bool(printed)
+
+
+def self_launch(n: int, argv) -> int:
+    """`python bench.py --gpus N`: start the N ranks (see _launch_once).  Ranks are pinned to one GPU each through
+    HIP_VISIBLE_DEVICES; should that attempt die before rank 0 has printed anything (a collective backend that cannot cope with
+    per-process device masks shows at the rendezvous / weight broadcast, in the first seconds), ONE second attempt runs with
+    the binding left to LOCAL_RANK -> torch.cuda.set_device, as under torch.distributed.run -- said loudly on stderr."""
+    pin = os.environ.get("SMOLTTS_BENCH_PIN_DEVICES", "1") != "0" and os.environ.get("SMOLTTS_BENCH_ONE_DEVICE") != "1"
+    rc, took, printed = _launch_once(n, argv, pin)
+    if rc != 0 and rc < 128 and pin and not printed and os.environ.get("SMOLTTS_BENCH_NO_FALLBACK") != "1":
+        print(f"[bench launcher] the pinned attempt failed with {rc} after {took:.0f} s before any result: "
+              "retrying ONCE without per-rank HIP_VISIBLE_DEVICES masks (binding by LOCAL_RANK)", file=sys.stderr, flush=True)
+        rc, _, _ = _launch_once(n, argv, False)
     return rc
 
 
@@ -197,6 +215,8 @@ def rehearse(args) -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if os.environ.get("SMOLTTS_BENCH_FAIL_RANK") == str(rank):  # test hook of the launcher: a rank that dies early
         raise SystemExit(3)
+    if os.environ.get("SMOLTTS_BENCH_FAIL_IF_PINNED") == "1" and os.environ.get("SMOLTTS_BENCH_PINNED") == "1" and rank == 1:
+        raise SystemExit(5)  # test hook: a backend that cannot work under per-rank device masks
     seen = parallel.ranks_seen("cpu")
     cfg = named_config("tiny")
     arena = offsets = None

@@ -44,6 +44,19 @@ def test_a_failing_rank_ends_the_run_with_its_exit_code():
     assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
 
 
+def test_a_start_up_failure_under_device_masks_is_retried_once_without_them():
+    """If the pinned attempt dies before rank 0 has printed anything, the launcher tries once more with the binding left to
+    LOCAL_RANK (the torch.distributed.run way) and says so."""
+    r, _ = _run({"SMOLTTS_BENCH_FAIL_IF_PINNED": "1"}, "--gpus", "2", "--rehearse-launcher", "--batch", "3")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "retrying ONCE without per-rank HIP_VISIBLE_DEVICES masks" in r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["ranks_seen"] == 2
+    # ... and with the fallback switched off the failure stands
+    r, _ = _run({"SMOLTTS_BENCH_FAIL_IF_PINNED": "1", "SMOLTTS_BENCH_NO_FALLBACK": "1"}, "--gpus", "2", "--rehearse-launcher")
+    assert r.returncode == 5
+
+
 def test_under_an_external_launcher_the_process_is_a_rank():
     """torch.distributed.run sets WORLD_SIZE: bench.py must then NOT spawn anything (here: WORLD_SIZE=1 -> plain rank 0)."""
     r, _ = _run({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "1", "--rehearse-launcher")
