@@ -7,12 +7,13 @@
 # 2 frames (~460 dispatches) ahead of the GPU; nothing else about the run changes.
 # Run on the GPU box from the repo root:  bash tools/collect_pmc.sh [tag]   -> gpurun_out/pmc_{fetch,write}/, pmc_summary.*
 set -e
+# (raw traces and counter tables stay under /tmp on the GPU box: only summaries go to gpurun_out/, which is merged back up to 64 MiB)
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export SMOLTTS_MAX_FRAMES_IN_FLIGHT=2
 export SMOLTTS_FRAMES_PER_GRAPH=1   # one frame per graph launch: the bound above counts frames, and a multi-frame graph is that many at once
 ARGS="bench.py --cpu-frames 0 --no-latency --steps 2 --warmup 1"
-rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
-timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o pmc -- python3 $ARGS > gpurun_out/pmc_fetch.log 2>&1 < /dev/null
-timeout -k 10 280 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o pmc -- python3 $ARGS > gpurun_out/pmc_write.log 2>&1 < /dev/null
-python3 tools/summarize_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_summary "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of \`python3 $ARGS\` with SMOLTTS_MAX_FRAMES_IN_FLIGHT=2; read = 2 x FETCH_SIZE (gfx950)"
+rm -rf /tmp/pmc_fetch /tmp/pmc_write
+timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fetch -o pmc -- python3 $ARGS > gpurun_out/pmc_fetch.log 2>&1 < /dev/null
+timeout -k 10 280 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_write -o pmc -- python3 $ARGS > gpurun_out/pmc_write.log 2>&1 < /dev/null
+python3 tools/summarize_pmc.py /tmp/pmc_fetch /tmp/pmc_write gpurun_out/pmc_summary "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of \`python3 $ARGS\` with SMOLTTS_MAX_FRAMES_IN_FLIGHT=2; read = 2 x FETCH_SIZE (gfx950)"
