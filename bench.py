@@ -318,7 +318,7 @@ def run_rank(args) -> None:
         state = synthetic_lm_state(cfg, seed=0)
         arena, offsets = pack_lm(cfg, state, numerics, args.weights)
         mstate = synthetic_mimi_state(seed=0)
-        m_arena, m_offsets = pack_mimi(mstate, 8, max_positions=2 * total_frames + 16)
+        m_arena, m_offsets = pack_mimi(mstate, 8, max_positions=2 * max(total_frames, 160) + 16)  # (the latency probe streams 150 frames)
         log(f"packed: LM arena {arena.numel() / 1e6:.1f} MB, Mimi arena {m_arena.numel() / 1e6:.1f} MB")
     arena, offsets = parallel.broadcast_weights(arena, offsets, dev)
     m_arena, m_offsets = parallel.broadcast_weights(m_arena, m_offsets, dev)
