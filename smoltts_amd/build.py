@@ -26,8 +26,7 @@ LIB = CSRC / "libsmoltts_hip.so"
 SOURCES = ["api.hip", "gemm.hip", "gemm_b3.hip", "gemm3.hip", "attention.hip", "small_ops.hip", "lm_engine.hip", "mimi_engine.hip", "mimi_encoder.hip",
            "seanet.hip", "seanet_last.hip", "conv_xs.hip"]
 ARCH = "gfx950"
-PRODUCT_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result",
-                 "-DSMOLTTS_NT_KV=1"]  # slow KV cache read with the non-temporal hint (measured +1..2 %: profiles/r03_ab_nt_kv.txt)
+PRODUCT_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 NAMED_VARIANTS = {"hooks": ["-DSMOLTTS_DEBUG_HOOKS"],  # event hooks + in-kernel cycle stamps for tools/
                   "knobs": ["-DSMOLTTS_DBG_KNOBS"]}    # the experiment environment switches of tools/ (forced tiles, kernels off)
 

@@ -33,10 +33,11 @@ struct AttnDev {
   int* split_ticket;   // [pairs] arrival tickets, counting up across launches (NS arrivals per pair and launch)
 };
 
-// The slow cache is read once per frame and is far larger than anything that could stay cached: with SMOLTTS_NT_KV its loads
-// carry the non-temporal hint, so that a frame's 100-400 MB of K / V rows do not sweep the weights out of the Infinity Cache.
+// The slow cache is read once per frame and is far larger than anything that could stay cached: its loads carry the
+// non-temporal hint, so that a frame's 100-400 MB of K / V rows do not sweep the weights out of the Infinity Cache
+// (measured +1..2 % frames/s, profiles/r03_ab_nt_kv.txt; -DSMOLTTS_NT_KV=0 builds the variant without it).
 #ifndef SMOLTTS_NT_KV
-#define SMOLTTS_NT_KV 0
+#define SMOLTTS_NT_KV 1
 #endif
 typedef float f32x4_nt __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
