@@ -57,10 +57,30 @@ def run(with_mimi):
     return frame_us[2:], mimi_us[2:]
 
 
+def codec_alone():
+    """The same codec passes (same stream positions) back to back, no frame graphs in between."""
+    ms = MimiSession(meng, max_batch=32, max_chunk_frames=CH)
+    codes = torch.randint(0, 2048, (32, (STEPS + 2) * CH, 9), dtype=torch.int32, device="cuda")
+    pcm = torch.zeros(32, 700 * 1920, device="cuda")
+    ms.reset()
+    out = []
+    for st in range(STEPS + 2):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ms.decode_chunk(codes, st * CH, CH, pcm, code_offset=1)
+        b.record()
+        torch.cuda.synchronize()
+        out.append(a.elapsed_time(b) * 1e3)
+    ms.close()
+    return np.array(out[4:])  # the positions of run()'s measured steps
+
+
 fa, ma = run(True)
 fb, _ = run(False)
+mc = codec_alone()
 print("frame time by position inside a chunk (us, mean over steps), with a codec pass after every chunk / without any:")
 for f in list(range(8)) + [15, 31]:
     print(f"  frame {f:2d}: {fa[:, f].mean():8.1f}   {fb[:, f].mean():8.1f}")
 print(f"sum of the 32 frames: {fa.sum(1).mean():.0f} us with codec passes, {fb.sum(1).mean():.0f} us without -> {fa.sum(1).mean() - fb.sum(1).mean():.0f} us lost by the frames")
-print(f"codec pass in situ: {ma.mean():.0f} us (stand-alone, caches warm: tools/time_mimi.py)")
+print(f"codec pass in situ: {ma.mean():.0f} us; the same passes (same stream positions) back to back without frame graphs: {mc.mean():.0f} us")
+print("  by step (in situ / alone): " + "  ".join(f"{a:.0f}/{b:.0f}" for a, b in zip(ma, mc)))
