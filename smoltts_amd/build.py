@@ -24,7 +24,7 @@ from typing import Optional, Sequence
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libsmoltts_hip.so"
 SOURCES = ["api.hip", "gemm.hip", "gemm_b3.hip", "gemm3.hip", "attention.hip", "small_ops.hip", "lm_engine.hip", "mimi_engine.hip", "mimi_encoder.hip",
-           "seanet.hip", "seanet_last.hip", "conv_xs.hip"]
+           "seanet.hip", "seanet_last.hip", "conv_xs.hip", "conv_ks.hip"]
 ARCH = "gfx950"
 PRODUCT_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 NAMED_VARIANTS = {"hooks": ["-DSMOLTTS_DEBUG_HOOKS"],  # event hooks + in-kernel cycle stamps for tools/

@@ -29,6 +29,13 @@ constexpr int XS_MAX_CIN = 256, XS_MAX_K_LINEAR = 512;
 
 __device__ __forceinline__ float elu_hw_xs(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
 
+#ifdef SMOLTTS_DBG_XS_STAMPS  // (diagnostic variant, tools/stamps_xs.py: cycles per phase as seen by thread 0 of every workgroup)
+__device__ unsigned long long g_xs_stamps[8 * 8];  // [epilogue][phase 0..5, 6 = workgroups, 7 unused]
+#define XS_STAMP(I) { const long long now_ = clock64(); st_sum[I] += now_ - st_last; st_last = now_; }
+#else
+#define XS_STAMP(I)
+#endif
+
 // MT 16-row tiles of output rows per workgroup, NTW column tiles per wave, RA LDS rows per plane, EPI the epilogue (gemm_dev.h)
 template <int NTW, int MT, int RA, int EPI>
 __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
@@ -44,6 +51,9 @@ __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
   const int nt0 = (p.ksplit > 1 ? 0 : (int)blockIdx.z * 8 * NTW) + wave * NTW;  // the wave's first column tile
   const int nloc = p.ksplit > 1 ? p.cpt : nchunks;                               // chunks this workgroup runs over
   const float* xb = p.x + (long)b * p.x_bstride + (long)row0 * p.ldx + (long)kz * p.cpt * 32;
+#ifdef SMOLTTS_DBG_XS_STAMPS
+  long long st_sum[6] = {0, 0, 0, 0, 0, 0}, st_last = clock64();
+#endif
 
   // ---- the tile's window rows -> pieces; 8 consecutive lanes take 8 consecutive rows of one 8-channel group (128 contiguous
   //      LDS bytes per ds_write_b128 lane group)
@@ -131,6 +141,7 @@ __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
     xp[slot + 2 * G * XS_RA] = l;
   }
 
+  XS_STAMP(0)
   f32x4 acc[XS_MT][NTW];
 #pragma unroll
   for (int mt = 0; mt < XS_MT; ++mt)
@@ -146,6 +157,7 @@ __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) wq[0][t][pc] = *reinterpret_cast<const uint4*>(wtile + (size_t)(t * nchunks) * 3072 + pc * 1024 + wlane);
   lds_barrier();  // (the W3 loads above stay in flight)
+  XS_STAMP(1)
 
   // (every workgroup streams the same W3 tiles in the same order; starting each tile's K loop at a different chunk, so that
   // they do not ask the same L2 lines at the same time, was measured: no difference)
@@ -172,8 +184,32 @@ __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
   }
   if (kc < nloc) XS_CHUNK(0, kc)
 #undef XS_CHUNK
+  XS_STAMP(2)
 
   // ---- epilogue from the accumulators: the lane holds out[row mt * 16 + r][n0 .. n0 + 4)
+  if (EPI == SMOLTTS_EPI_RESID && p.ksplit <= 1 && (p.N & 15) == 0) {  // all residual values first (one round trip), then the stores
+    float4 rr[XS_MT][NTW];
+#pragma unroll
+    for (int mt = 0; mt < XS_MT; ++mt) {
+      const int rl = row0 + mt * 16 + r;
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        rr[mt][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rl < T) rr[mt][t] = *reinterpret_cast<const float4*>(p.resid + row_off(b * T + rl, p.rows_per_batch, p.ldr, p.r_bstride) + (nt0 + t) * 16 + q * 4);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < XS_MT; ++mt) {
+      const int rl = row0 + mt * 16 + r;
+      if (rl >= T) continue;
+      const long orow = row_off(b * T + rl, p.rows_per_batch, p.ldo, p.o_bstride);
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        float v[4] = {acc[mt][t][0], acc[mt][t][1], acc[mt][t][2], acc[mt][t][3]};
+        rows_epilogue_resid(p, orow, (nt0 + t) * 16 + q * 4, v, rr[mt][t]);
+      }
+    }
+  } else {
 #pragma unroll
   for (int mt = 0; mt < XS_MT; ++mt) {
     const int rl = row0 + mt * 16 + r;
@@ -191,6 +227,15 @@ __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
       rows_epilogue<EPI>(p, m, orow, n0, v);
     }
   }
+  }
+#ifdef SMOLTTS_DBG_XS_STAMPS
+  XS_STAMP(3)
+  if (tid == 0) {
+    const int st_row = p.ksplit > 1 ? 6 : (EPI == 0 && NTW == 1) ? 2 : EPI;  // (fc2's K parts and the N = 128 conv get rows of their own)
+    for (int i = 0; i < 4; ++i) atomicAdd(&g_xs_stamps[st_row * 8 + i], (unsigned long long)st_sum[i]);
+    atomicAdd(&g_xs_stamps[st_row * 8 + 6], 1ull);
+  }
+#endif
 }
 
 template <int NTW, int MT, int RA, int EPI>
@@ -288,3 +333,14 @@ int launch_conv_xs(const GemmDev& d, int epilogue, hipStream_t stream) {
 }
 
 }  // namespace smoltts
+
+#ifdef SMOLTTS_DBG_XS_STAMPS
+extern "C" int smoltts_debug_xs_stamps(unsigned long long* out64, int reset) {
+  if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(smoltts::g_xs_stamps), 64 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[64] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(smoltts::g_xs_stamps), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

@@ -216,6 +216,7 @@ bool gemm_b3_applies(int M, int N, int K, int epilogue) {
 int launch_gemm_b3(const GemmDev& d, int epilogue, hipStream_t stream) {
   ST_REQUIRE(d.w3 && gemm_b3_applies(d.M, d.N, d.K, epilogue), SMOLTTS_E_INVALID, "gemm_b3: shape or epilogue not supported");
   if (conv_xs_applies(d, epilogue)) return launch_conv_xs(d, epilogue, stream);
+  if (conv_ks_applies(d, epilogue)) return launch_conv_ks(d, epilogue, stream);
   switch (epilogue) {
     case SMOLTTS_EPI_STORE: return launch_b3_epi<SMOLTTS_EPI_STORE>(d, stream);
     case SMOLTTS_EPI_RESID: return launch_b3_epi<SMOLTTS_EPI_RESID>(d, stream);

@@ -56,6 +56,10 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+// ELU of the many-row epilogues, with the hardware exponential: exp(x) - 1 carries an absolute error of ~1 ulp of 1 (6e-8)
+// where expm1f is relatively exact -- the size of the fp32 rounding of the O(1) activations around it, at a fifth of the
+// instructions (a k1 conv's workgroup applies it to 64 values per lane; seanet.hip and the ELU prologues do the same).
+__device__ __forceinline__ float elu_rows(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
 __device__ __forceinline__ float silu1(float x) { return x / (1.f + expf(-x)); }
 __device__ __forceinline__ float gelu1(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
@@ -71,7 +75,7 @@ __device__ __forceinline__ void rows_epilogue(const GemmDev& p, int m, long orow
       if (n0 + i < p.N) v[i] += p.bias[n0 + i];
   }
   if (n0 + 4 > p.N) {  // N < 4: scalar tail (the 1-channel output conv)
-    for (int i = 0; i < 4 && n0 + i < p.N; ++i) p.out[orow + n0 + i] = p.elu_out ? elu1(v[i]) : v[i];
+    for (int i = 0; i < 4 && n0 + i < p.N; ++i) p.out[orow + n0 + i] = p.elu_out ? elu_rows(v[i]) : v[i];
     return;
   }
   if (EPI == SMOLTTS_EPI_GELU) {
@@ -111,7 +115,20 @@ __device__ __forceinline__ void rows_epilogue(const GemmDev& p, int m, long orow
   } else if (p.raw_out) {
     *reinterpret_cast<float4*>(p.raw_out + row_off(m, p.rows_per_batch, p.ldo, p.raw_bstride) + n0) = make_float4(v[0], v[1], v[2], v[3]);
   }
-  if (p.elu_out) { v[0] = elu1(v[0]); v[1] = elu1(v[1]); v[2] = elu1(v[2]); v[3] = elu1(v[3]); }
+  if (p.elu_out) { v[0] = elu_rows(v[0]); v[1] = elu_rows(v[1]); v[2] = elu_rows(v[2]); v[3] = elu_rows(v[3]); }
+  *reinterpret_cast<float4*>(p.out + orow + n0) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// The residual epilogue with the residual values already in registers (a workgroup with many output tiles per lane loads
+// them all before the first store: one memory round trip instead of one per tile -- `out` may alias nothing the loads read,
+// but the compiler cannot know): same arithmetic as rows_epilogue<SMOLTTS_EPI_RESID>.
+__device__ __forceinline__ void rows_epilogue_resid(const GemmDev& p, long orow, int n0, float v[4], const float4 rr) {
+  if (p.bias) {
+    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n0);
+    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+  }
+  v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+  if (p.elu_out) { v[0] = elu_rows(v[0]); v[1] = elu_rows(v[1]); v[2] = elu_rows(v[2]); v[3] = elu_rows(v[3]); }
   *reinterpret_cast<float4*>(p.out + orow + n0) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
@@ -152,5 +169,7 @@ int launch_gemm_b3(const GemmDev& d, int epilogue, hipStream_t stream);  // gemm
 bool gemm_b3_applies(int M, int N, int K, int epilogue);
 int launch_conv_xs(const GemmDev& d, int epilogue, hipStream_t stream);  // conv_xs.hip: conv windows of <= 256 channels / Linears of K <= 512, X stationary in LDS
 bool conv_xs_applies(const GemmDev& d, int epilogue);
+int launch_conv_ks(const GemmDev& d, int epilogue, hipStream_t stream);  // conv_ks.hip: conv windows over > 256 channels, X through LDS in 128-channel slices
+bool conv_ks_applies(const GemmDev& d, int epilogue);
 
 }  // namespace smoltts

@@ -86,11 +86,16 @@ def test_b3_elu_prologue_and_residual(E, ops):
 
 
 @pytest.mark.parametrize("taps,cin,N,T,B", [(3, 256, 128, 2203, 3), (2, 128, 320, 1301, 2), (7, 64, 64, 3101, 4),
-                                             (3, 256, 128, 5500, 3), (2, 256, 640, 3001, 6), (3, 128, 128, 1111, 16)])  # the last three: conv_xs.hip
+                                             (3, 256, 128, 5500, 3), (2, 256, 640, 3001, 6), (3, 128, 128, 1111, 16),  # these three: conv_xs.hip
+                                             # conv_ks.hip (> 256 channels in 128-channel slices): the four SEANet layers at the
+                                             # benchmark's chunk (conv0, ConvTranspose 1, res1's k3 conv, ConvTranspose 2), ragged tiles
+                                             (7, 512, 1024, 64, 32), (2, 1024, 4096, 64, 32), (3, 512, 256, 512, 32), (2, 512, 1536, 512, 32),
+                                             (3, 512, 256, 333, 48), (2, 384, 128, 100, 130)])
 def test_b3_conv_windows_over_halo_prefixed_slots(E, ops, taps, cin, N, T, B):
     """Causal conv as a GEMM over overlapping windows (row stride = cin, K = taps * cin) of per-slot buffers with taps - 1 halo
     rows: the kernel visits the taps of a channel slice back to back (a different K order than the fp32 kernel) -- same result.
-    With <= 256 channels, N = 128 | 640 and >= 256 tiles of 64 rows the window-stationary kernel (conv_xs.hip) takes the call."""
+    With <= 256 channels, N = 128 | 640 and >= 256 tiles of 64 rows the window-stationary kernel (conv_xs.hip) takes the call;
+    with more channels (a multiple of 128) and >= 256 workgroups of 64 rows x 128..512 columns the sliced one (conv_ks.hip)."""
     g = torch.Generator().manual_seed(taps * 1000 + cin)
     rows = T + taps - 1
     buf = torch.randn(B, rows, cin, generator=g)
