@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SMOLTTS_ABI_VERSION 3
+#define SMOLTTS_ABI_VERSION 4
 
 enum {
   SMOLTTS_OK = 0,
@@ -410,7 +410,13 @@ typedef struct SmolttsGemmArgs {
   int64_t splitk_ws_floats;   /* ... and its size in floats (4 * M * N needed; smaller = no split) */
   const float* beta_dev;      /* PRO_LAYERNORM: bias [K] */
   float* ln_scratch_dev;      /* PRO_LAYERNORM: [M][K] floats for the calls whose kernel has no such prologue */
+  void* k_cache3_dev;         /* EPI_QKV_ROPE, optional (both or neither): the same K / V rows also as bf16x3 PIECE caches, the operands */
+  void* v_cache3_dev;         /* of smoltts_k_attention_rows3 (layouts there); SMOLTTS_KV3_BYTES(slots, n_kv, cache_len) bytes each, */
+                              /* zero-filled once by the owner (unwritten positions are multiplied by zero weights: they must be finite) */
 } SmolttsGemmArgs;
+
+/* bytes of one bf16x3 piece cache: per (slot, kv head) 6 bytes per value over cache_len rounded up to whole 32-position blocks */
+#define SMOLTTS_KV3_BYTES(slots, n_kv, cache_len) ((size_t)(slots) * (size_t)(n_kv) * (size_t)(((cache_len) + 31) / 32 * 32) * 384u)
 
 int smoltts_k_gemm(const SmolttsGemmArgs* a, void* stream);
 
@@ -496,6 +502,22 @@ int smoltts_k_attention_split(const float* q_dev, const void* k_cache_dev, const
                               const int32_t* row_slot_dev, int32_t n_rows, int32_t n_q_heads, int32_t n_kv_heads, int32_t cache_len,
                               int32_t window, float* out_dev, void* out_x3_dev, int32_t kv_format, float* split_part_dev,
                               int32_t* split_ticket_dev, void* stream);
+
+/* Attention of MANY rows per slot (the codec transformer over a chunk: rows_per_slot consecutive positions per slot,
+ * rows_per_slot % 32 == 0, n_rows % rows_per_slot == 0, one query head per kv head) on the bf16 matrix cores over the PIECE
+ * caches an EPI_QKV_ROPE GEMM with k_cache3_dev / v_cache3_dev wrote: every K / V value as three bf16 pieces (hi + mid + lo ==
+ * the fp32 value exactly), six products per operand pair as in the many-row GEMMs, fp32 accumulation, flash-style softmax.
+ * Layouts, per (slot, head) at ((slot * n_heads + head) * ceil32(cache_len) * 384 bytes:
+ *   K3: positions in tiles of 16, the 64 dims in two chunks of 32: block (tile, chunk, piece) = 1 KiB at
+ *       ((tile * 2 + chunk) * 3 + piece) * 1024; lane l = 16 q + r holds the 8 bf16 K[16 tile + r][32 chunk + 8q .. + 8)
+ *       (the "X3" row format of smoltts_amd/csrc/x3.h with K = 64);
+ *   V3: positions in blocks of 32, dims in four tiles of 16: block (pb, dim tile t, piece) = 1 KiB at
+ *       ((pb * 4 + t) * 3 + piece) * 1024; lane l = 16 q + r holds, for j = 0..7, V[32 pb + (j < 4 ? 4q + j : 16 + 4q + j - 4)][16 t + r]
+ *       (the key order in which a lane of the score MFMA holds its eight probabilities of a 32-key block).
+ * Same keys as smoltts_k_attention: [max(0, pos + 1 - window), pos] of the row's slot. */
+int smoltts_k_attention_rows3(const float* q_dev, const void* k_cache3_dev, const void* v_cache3_dev, const int32_t* row_pos_dev,
+                              const int32_t* row_slot_dev, int32_t n_rows, int32_t rows_per_slot, int32_t n_heads, int32_t cache_len,
+                              int32_t window, float* out_dev, void* stream);
 
 /* x[r] = E_text[cols[r][0]] + keep * sum_k E_cb[cols[r][1+k] + k*codebook_size] */
 int smoltts_k_embed(const int32_t* cols_dev, int32_t n_rows, int32_t n_code_rows,

@@ -40,6 +40,13 @@ int smoltts_k_attention_kv(const float* q_dev, const void* k_cache_dev, const vo
                           window, out_dev, out_x3_dev, (hipStream_t)stream, kv_format);
 }
 
+int smoltts_k_attention_rows3(const float* q_dev, const void* k_cache3_dev, const void* v_cache3_dev, const int32_t* row_pos_dev,
+                              const int32_t* row_slot_dev, int32_t n_rows, int32_t rows_per_slot, int32_t n_heads, int32_t cache_len,
+                              int32_t window, float* out_dev, void* stream) {
+  return launch_attention_rows3(q_dev, k_cache3_dev, v_cache3_dev, row_pos_dev, row_slot_dev, n_rows, rows_per_slot, n_heads, cache_len,
+                                window, out_dev, (hipStream_t)stream);
+}
+
 int smoltts_k_attention_split(const float* q_dev, const void* k_cache_dev, const void* v_cache_dev, const int32_t* row_pos_dev,
                               const int32_t* row_slot_dev, int32_t n_rows, int32_t n_q_heads, int32_t n_kv_heads, int32_t cache_len,
                               int32_t window, float* out_dev, void* out_x3_dev, int32_t kv_format, float* split_part_dev,

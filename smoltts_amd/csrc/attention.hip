@@ -14,6 +14,7 @@
 // hardware exp2 path (__expf): its error is |x| * 2^-24 relative on e^x with x <= 0, i.e. at most 2.2e-8
 // absolute on a softmax weight -- below the fp32 rounding of the weights themselves.
 // The result is written as fp32 rows and/or directly as the X3 operand of the following wo GEMM.
+#include "gemm_dev.h"  // split3x8, mfma_b3 (the bf16x3 product scheme of the many-row GEMMs)
 #include "x3.h"
 
 namespace smoltts {
@@ -681,6 +682,202 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(AttnDev p, int n_rows
   }
 }
 
+// Many rows per slot over bf16x3 PIECE caches (the codec transformer over a chunk; layouts: include/smoltts_hip.h at
+// smoltts_k_attention_rows3): the same flash-style scheme on v_mfma_f32_16x16x32_bf16 with both operands in three bf16 pieces
+// (six products per pair: exact products, fp32 accumulation, dropped terms < 2^-24 relative -- gemm_dev.h), 384 instead of 1024
+// matrix-pipe cycles per 16 keys and row tile, and no conversion work on K / V: their pieces were written once, by the QKV
+// GEMM's epilogue.  One workgroup per (slot, head, RT consecutive 16-row tiles); its 4 waves take every 4th block of 32 keys;
+// a block's K3 / V3 fragments are loaded once for all RT row tiles.  Fragment bookkeeping, lane l = 16 q + r:
+//   S:  A = K3 (lane: K[key r of a 16-key tile][32 c + 8q .. + 8)), B = Q3 (Q[row r][32 c + 8q .. + 8)); D[i] = S[key 4q + i][row r]
+//   O:  A = V3 (lane: V[the 8 keys of slot q][dim 16 t + r]), B = P3 (the lane's own 8 probabilities: keys 4q .. 4q + 3 of the
+//       block's two 16-key tiles); D[i] = O[dim 16 t + 4q + i][row r]  ->  the lane owns out[row r][16 t + 4q .. + 4), t = 0..3
+// so again no value crosses lanes except the row maximum.
+#ifndef SMOLTTS_NT_KV3
+#define SMOLTTS_NT_KV3 0  // (1 = the piece caches are read with the non-temporal hint: measured)
+#endif
+__device__ __forceinline__ uint4 ld_u4_kv3(const char* p) {
+#if SMOLTTS_NT_KV3
+  const u32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+#else
+  return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+
+struct Rows3Dev {
+  const float* q;
+  const char* kc3;
+  const char* vc3;
+  const int* row_pos;
+  const int* row_slot;
+  float* out;
+  int n_heads, cache_len, window, rows_per_slot, n_units, members;  // units = (slot group, head); members = row groups per slot
+};
+
+template <int RT>
+__global__ __launch_bounds__(256) void attn_rows3_kernel(Rows3Dev p) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  __shared__ float merge[4][64][RT * 18];
+  // XCD-aware order: the row groups of one (slot, head) read the same K3 / V3: consecutive slots on ONE XCD (ids are dealt
+  // round-robin over the 8 XCDs)
+  const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+  const int mem = kk % p.members, unit = (kk / p.members) * 8 + xcd;
+  if (unit >= p.n_units) return;  // (grid padded to whole groups of 8 units; uniform over the workgroup)
+  const int sg = unit / p.n_heads, head = unit - sg * p.n_heads;
+  const int row0 = sg * p.rows_per_slot + mem * 16 * RT;
+  const int HD = p.n_heads * 64;
+  const int slot = p.row_slot[row0];
+
+  int pos[RT], jlo[RT];
+  bool valid[RT];
+  int lo = 0x7fffffff, hi = -1;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    pos[rt] = p.row_pos[row0 + rt * 16 + r];
+    valid[rt] = pos[rt] >= 0 && pos[rt] < p.cache_len;
+    jlo[rt] = (p.window > 0 && pos[rt] + 1 > p.window) ? pos[rt] + 1 - p.window : 0;
+    if (valid[rt]) { lo = min(lo, jlo[rt]); hi = max(hi, pos[rt]); }
+  }
+#pragma unroll
+  for (int ofs = 8; ofs > 0; ofs >>= 1) {  // over the 16 rows (all four q copies hold the same values)
+    lo = min(lo, __shfl_xor(lo, ofs));
+    hi = max(hi, __shfl_xor(hi, ofs));
+  }
+
+  // Q[row r][32 c + 8q .. + 8) / 8 in pieces, through LDS (the four waves work on the same rows; in registers the 12 fragments
+  // would push the kernel past 256 registers = one wave per SIMD): wave w splits (row tile, chunk) pair w, w + 4, ..
+  __shared__ uint4 qs[RT * 2 * 3 * 64];
+  for (int pr2 = wave; pr2 < RT * 2; pr2 += 4) {
+    const int rt = pr2 >> 1, c = pr2 & 1;
+    const float* qp = p.q + (long)(row0 + rt * 16 + r) * HD + head * 64 + c * 32 + q * 8;
+    float4 a = *reinterpret_cast<const float4*>(qp), b = *reinterpret_cast<const float4*>(qp + 4);
+    a = make_float4(a.x * 0.125f, a.y * 0.125f, a.z * 0.125f, a.w * 0.125f);
+    b = make_float4(b.x * 0.125f, b.y * 0.125f, b.z * 0.125f, b.w * 0.125f);
+    uint4 h, m, l;
+    split3x8(a, b, h, m, l);
+    qs[(pr2 * 3 + 0) * 64 + lane] = h;
+    qs[(pr2 * 3 + 1) * 64 + lane] = m;
+    qs[(pr2 * 3 + 2) * 64 + lane] = l;
+  }
+  __syncthreads();
+  f32x4 o[RT][4];
+  float mrow[RT], lpart[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    mrow[rt] = -INFINITY; lpart[rt] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o[rt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  const long per_head = (long)((p.cache_len + 31) & ~31) * 384;
+  const char* kb = p.kc3 + ((long)slot * p.n_heads + head) * per_head + lane * 16;
+  const char* vb = p.vc3 + ((long)slot * p.n_heads + head) * per_head + lane * 16;
+  uint4 kf[2][2][3], vf[4][3];  // K3 [16-key tile][chunk][piece], V3 [dim tile][piece] of the current 32-key block
+#define R3_LOAD_K(PB)                                                                                   \
+  _Pragma("unroll") for (int tl = 0; tl < 2; ++tl)                                                      \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                       \
+      _Pragma("unroll") for (int pc = 0; pc < 3; ++pc)                                                  \
+        kf[tl][c][pc] = ld_u4_kv3(kb + ((long)(((PB) * 2 + tl) * 2 + c) * 3 + pc) * 1024);
+#define R3_LOAD_V(PB)                                                                                   \
+  _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                         \
+    _Pragma("unroll") for (int pc = 0; pc < 3; ++pc)                                                    \
+      vf[t][pc] = ld_u4_kv3(vb + ((long)((PB) * 4 + t) * 3 + pc) * 1024);
+  const int b_hi = hi >> 5;  // hi < 0 (no valid row): no block
+  int pb = (lo >> 5) + wave;
+  if (hi >= 0 && pb <= b_hi) { R3_LOAD_K(pb) R3_LOAD_V(pb) }
+  for (; hi >= 0 && pb <= b_hi; pb += 4) {
+    f32x4 sc[RT][2];
+    int fresh = 0;  // (an offset the compiler cannot see through: the Q3 reads stay in the loop instead of living in 48 registers)
+    asm volatile("" : "+v"(fresh));
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          uint4 qf[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) qf[pc] = qs[((rt * 2 + c) * 3 + pc) * 64 + lane + fresh];
+          a = mfma_b3(kf[tl][c], qf, a);
+        }
+        sc[rt][tl] = a;
+      }
+    if (pb + 4 <= b_hi) { R3_LOAD_K(pb + 4) }  // (the K3 registers are free: the next block's fragments fly under the softmax and O)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      float sv[8];
+      float bm = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int j = pb * 32 + (i >> 2) * 16 + 4 * q + (i & 3);
+        sv[i] = (valid[rt] && j >= jlo[rt] && j <= pos[rt]) ? sc[rt][i >> 2][i & 3] : -INFINITY;
+        bm = fmaxf(bm, sv[i]);
+      }
+      bm = fmaxf(bm, __shfl_xor(bm, 16));
+      bm = fmaxf(bm, __shfl_xor(bm, 32));
+      const float mn = fmaxf(mrow[rt], bm);
+      const float rs = mn > -INFINITY ? __expf(mrow[rt] - mn) : 1.f;  // exp(-inf - finite) = 0 on a row's first block
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sv[i] = mn > -INFINITY ? __expf(sv[i] - mn) : 0.f;
+      lpart[rt] = lpart[rt] * rs + (((sv[0] + sv[1]) + (sv[2] + sv[3])) + ((sv[4] + sv[5]) + (sv[6] + sv[7])));
+      mrow[rt] = mn;
+      uint4 pf[3];
+      split3x8(make_float4(sv[0], sv[1], sv[2], sv[3]), make_float4(sv[4], sv[5], sv[6], sv[7]), pf[0], pf[1], pf[2]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x4 a = o[rt][t];
+        a[0] *= rs; a[1] *= rs; a[2] *= rs; a[3] *= rs;
+        o[rt][t] = mfma_b3(vf[t], pf, a);
+      }
+    }
+    if (pb + 4 <= b_hi) { R3_LOAD_V(pb + 4) }
+  }
+#undef R3_LOAD_K
+#undef R3_LOAD_V
+
+  // merge the 4 waves' partials (same lane = same rows and columns in every wave), then normalise and store
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    float* mp = &merge[wave][lane][rt * 18];
+    mp[0] = mrow[rt]; mp[1] = lpart[rt];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mp[2 + t * 4 + i] = o[rt][t][i];
+  }
+  __syncthreads();
+  if (wave >= RT) return;  // wave w finishes row tile w
+  {
+    const int rt = wave;
+    float gm = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) gm = fmaxf(gm, merge[w][lane][rt * 18]);
+    float l = 0.f;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* mp = &merge[w][lane][rt * 18];
+      const float f = mp[0] > -INFINITY ? __expf(mp[0] - gm) : 0.f;
+      l = fmaf(mp[1], f, l);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = fmaf(mp[2 + j], f, acc[j]);
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const bool ok = l > 0.f;
+    const float inv = ok ? 1.0f / l : 0.f;
+    float* orow = p.out + (long)(row0 + rt * 16 + r) * HD + head * 64 + 4 * q;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      *reinterpret_cast<float4*>(orow + 16 * t) = make_float4(ok ? __fmul_rn(acc[t * 4 + 0], inv) : 0.f, ok ? __fmul_rn(acc[t * 4 + 1], inv) : 0.f,
+                                                              ok ? __fmul_rn(acc[t * 4 + 2], inv) : 0.f, ok ? __fmul_rn(acc[t * 4 + 3], inv) : 0.f);
+  }
+}
+
 // Caches of at most 16 entries (the depth transformer's per-frame cache, lm/generate.py:112): one wave
 // per (row, kv head), all K/V rows loaded up front, no LDS and no barrier -- the kernel is a single
 // memory round trip plus wave shuffles.
@@ -847,6 +1044,20 @@ int launch_attention(const float* q, const void* kc, const void* vc, const int32
       return SMOLTTS_E_INVALID;
   }
 #undef ST_ATTN
+  ST_CHECK_HIP(hipGetLastError());
+  return SMOLTTS_OK;
+}
+
+int launch_attention_rows3(const float* q, const void* kc3, const void* vc3, const int32_t* row_pos, const int32_t* row_slot, int n_rows,
+                           int rows_per_slot, int n_heads, int cache_len, int window, float* out, hipStream_t stream) {
+  ST_REQUIRE(q && kc3 && vc3 && row_pos && row_slot && out, SMOLTTS_E_INVALID, "attention_rows3: null pointer");
+  ST_REQUIRE(n_rows > 0 && n_heads > 0 && cache_len > 0 && rows_per_slot > 0 && rows_per_slot % 32 == 0 && n_rows % rows_per_slot == 0,
+             SMOLTTS_E_INVALID, "attention_rows3: bad shape rows=%d rows_per_slot=%d heads=%d cache_len=%d", n_rows, rows_per_slot, n_heads, cache_len);
+  Rows3Dev d{q, (const char*)kc3, (const char*)vc3, row_pos, row_slot, out, n_heads, cache_len, window, rows_per_slot,
+             (n_rows / rows_per_slot) * n_heads, rows_per_slot / 32};
+  const long blocks = (long)((d.n_units + 7) / 8) * 8 * d.members;
+  ST_REQUIRE(blocks < (1L << 30), SMOLTTS_E_INVALID, "attention_rows3: grid too large");
+  hipLaunchKernelGGL((attn_rows3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, stream, d);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
 }

@@ -286,6 +286,7 @@ __global__ __launch_bounds__(MT >= 4 ? 512 : 1024) void gemm_kernel(GemmDev p) {
       float* base = nn < kd ? p.kc : p.vc;
       const int h = (nn < kd ? nn : nn - kd) >> 6, d = nn & 63;
       *reinterpret_cast<float4*>(base + (((long)slot * p.n_kv_heads + h) * p.cache_len + pos) * 64 + d) = o;
+      if (p.kc3) kv3_store(p.kc3, p.vc3, p.n_kv_heads, p.cache_len, slot, h, pos, d, nn >= kd, o);
     }
   }
   STAMP(5);
@@ -506,7 +507,7 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
   d.ln_w = nullptr; d.ln_b = nullptr;
   d.o_bstride = a.o_bstride; d.ldr = a.ldr ? a.ldr : a.ldo; d.r_bstride = a.ldr ? a.r_bstride : a.o_bstride;
   d.rope = a.rope_dev; d.row_pos = a.row_pos_dev; d.row_slot = a.row_slot_dev;
-  d.kc = a.k_cache_dev; d.vc = a.v_cache_dev; d.n_q_heads = a.n_q_heads; d.n_kv_heads = a.n_kv_heads;
+  d.kc = a.k_cache_dev; d.vc = a.v_cache_dev; d.kc3 = (char*)a.k_cache3_dev; d.vc3 = (char*)a.v_cache3_dev; d.n_q_heads = a.n_q_heads; d.n_kv_heads = a.n_kv_heads;
   d.cache_len = a.cache_len;
 #ifdef SMOLTTS_DEBUG_HOOKS
   d.stamps = g_stamps;
@@ -529,6 +530,7 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
                SMOLTTS_E_INVALID, "gemm: QKV_ROPE epilogue arguments inconsistent");
   else
     ST_REQUIRE(a.out_dev, SMOLTTS_E_INVALID, "gemm: null output");
+  ST_REQUIRE((a.k_cache3_dev == nullptr) == (a.v_cache3_dev == nullptr), SMOLTTS_E_INVALID, "gemm: the piece caches come in pairs");
 
   // many rows: the LDS-staged kernel, provided its grid (64*WM rows x 16*NTW*WN columns per workgroup,
   // K not split) still fills the chip; otherwise the K-split skinny kernel has the shorter critical path

@@ -30,6 +30,8 @@ struct GemmDev {
   const int* row_slot;
   float* kc;
   float* vc;
+  char* kc3;  // optional (EPI_QKV_ROPE): the K / V rows also as bf16x3 piece caches (include/smoltts_hip.h, smoltts_k_attention_rows3)
+  char* vc3;
   int n_q_heads, n_kv_heads, cache_len;
   unsigned long long* stamps;  // diagnostic build aid (SMOLTTS debug API); nullptr in production
   int grid_rb, grid_cb;        // gemm_b3: row blocks x column blocks of the (1-D, XCD-aware) launch
@@ -62,6 +64,28 @@ __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x);
 __device__ __forceinline__ float elu_rows(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
 __device__ __forceinline__ float silu1(float x) { return x / (1.f + expf(-x)); }
 __device__ __forceinline__ float gelu1(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+// K / V values [pos][d .. d + 4) of (slot, kv head h) into the bf16x3 piece caches (layouts: include/smoltts_hip.h at
+// smoltts_k_attention_rows3).  K: the X3 row format over positions; V: per 32-position block and 16-dim tile, lane 16 q + (dim % 16)
+// holds 8 positions in the order the score MFMA leaves a lane its probabilities.
+__device__ __forceinline__ void kv3_store(char* kc3, char* vc3, int n_kv_heads, int cache_len, int slot, int h, int pos, int d, bool is_v,
+                                          const float4 o) {
+  const long per_head = (long)((cache_len + 31) & ~31) * 384;
+  const long head = ((long)slot * n_kv_heads + h) * per_head;
+  if (!is_v) {
+    x3_emit4(kc3 + head, pos, d, 2, o.x, o.y, o.z, o.w);
+    return;
+  }
+  uint32_t h0, m0, l0, h1, m1, l1;
+  split3_pair(o.x, o.y, h0, m0, l0);
+  split3_pair(o.z, o.w, h1, m1, l1);
+  const int kk = pos & 31, key = kk & 15, j = (key & 3) + 4 * (kk >> 4);
+  unsigned short* dst = reinterpret_cast<unsigned short*>(vc3 + head + (long)((pos >> 5) * 4 + (d >> 4)) * 3072 + ((key >> 2) * 16 + (d & 15)) * 16 + j * 2);
+  // dims d .. d + 3 are the lanes r .. r + 3 of the fragment: 16 bytes (8 shorts) apart; pieces 1 KiB (512 shorts) apart
+  dst[0] = (unsigned short)h0; dst[8] = (unsigned short)(h0 >> 16); dst[16] = (unsigned short)h1; dst[24] = (unsigned short)(h1 >> 16);
+  dst[512] = (unsigned short)m0; dst[520] = (unsigned short)(m0 >> 16); dst[528] = (unsigned short)m1; dst[536] = (unsigned short)(m1 >> 16);
+  dst[1024] = (unsigned short)l0; dst[1032] = (unsigned short)(l0 >> 16); dst[1040] = (unsigned short)l1; dst[1048] = (unsigned short)(l1 >> 16);
+}
 
 // Epilogue of the many-row kernels, straight from the accumulators: the lane holds acc = X.W^T for out[m][n0 .. n0+4)
 // (`orow` = offset of row m in `out`).  Bias, then by EPI: GELU | layer-scale + residual | RoPE + q / KV-cache scatter |
@@ -106,6 +130,7 @@ __device__ __forceinline__ void rows_epilogue(const GemmDev& p, int m, long orow
       float* base = nn < kd ? p.kc : p.vc;
       const int h = (nn < kd ? nn : nn - kd) >> 6, d = nn & 63;
       *reinterpret_cast<float4*>(base + (((long)slot * p.n_kv_heads + h) * p.cache_len + pos) * 64 + d) = o;
+      if (p.kc3) kv3_store(p.kc3, p.vc3, p.n_kv_heads, p.cache_len, slot, h, pos, d, nn >= kd, o);
     }
     return;
   }

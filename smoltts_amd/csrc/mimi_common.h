@@ -12,6 +12,8 @@ struct MimiTransformerBufs {
   size_t layer_stride;            // floats between two layers' caches
   const int *row_pos, *row_slot;  // [rows]
   float* tws = nullptr;           // optional split-K workspace (4 x rows x 512 floats) for the fc2 GEMM of many-row calls
+  char *kc3 = nullptr, *vc3 = nullptr;  // optional bf16x3 piece caches [n_layers][slots][8][ceil32(cache_len)] x 384 bytes (zero-filled once):
+  size_t layer_stride3 = 0;             // the QKV GEMM writes them beside kc / vc, chunks of a multiple of 32 rows per slot attend over them
 };
 
 // The 8-layer pre-LayerNorm block stack of codec/transformer.py:109-150 over `rows` rows (`rows_per_slot`

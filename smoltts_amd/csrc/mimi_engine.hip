@@ -54,6 +54,8 @@ struct SmolttsMimiSession {
   float *tx, *tn, *tq, *ta, *th;  // transformer rows [B*2*chunk][512|512|512|512|2048]
   float* tws;        // split-K partial sums of the fc2 GEMM: [4][B*2*chunk][512]
   float *kc, *vc;    // [n_layers][B][8][max_positions][64]
+  char *kc3, *vc3;   // the same as bf16x3 pieces (sessions whose chunks reach 16 frames = 32 rows per slot; null otherwise), zeroed at creation
+  size_t kv3_layer;  // bytes per layer
   int *row_pos, *row_slot;  // [B*2*chunk]
   float* buf[NBUF];
   size_t buf_bstride[NBUF];  // floats per slot
@@ -109,6 +111,10 @@ void carve(SmolttsMimiSession* s, char* base, size_t* total) {
   s->vc = cv.take<float>(kv);
   s->row_pos = cv.take<int>(R);
   s->row_slot = cv.take<int>(R);
+  // piece caches for the many-row attention (attn_rows3_kernel): only where a chunk can have 32 rows per slot
+  s->kv3_layer = F >= 16 ? SMOLTTS_KV3_BYTES(B, HEADS, c.max_positions) : 0;
+  s->kc3 = s->kv3_layer ? cv.take<char>(s->kv3_layer * c.n_layers) : nullptr;
+  s->vc3 = s->kv3_layer ? cv.take<char>(s->kv3_layer * c.n_layers) : nullptr;
   *total = cv.off;
 }
 
@@ -197,10 +203,16 @@ int run_mimi_transformer(const char* A, const SmolttsMimiLayerWeights* layers, i
       a.epilogue = SMOLTTS_EPI_QKV_ROPE; a.out_dev = b.tq; a.ldo = D;
       a.rope_dev = rope; a.row_pos_dev = b.row_pos; a.row_slot_dev = b.row_slot;
       a.k_cache_dev = kc; a.v_cache_dev = vc;
+      if (b.kc3) { a.k_cache3_dev = b.kc3 + l * b.layer_stride3; a.v_cache3_dev = b.vc3 + l * b.layer_stride3; }
       a.n_q_heads = HEADS; a.n_kv_heads = HEADS; a.cache_len = cache_len;
       ST_TRY(launch_gemm(a, st));
     }
-    ST_TRY(launch_attention(b.tq, kc, vc, b.row_pos, b.row_slot, R, HEADS, HEADS, cache_len, window, b.ta, nullptr, st));
+    static const bool rows3_off = ST_KNOB_INT("SMOLTTS_ROWS3", 1) == 0;  // experiments (knobs builds only)
+    if (b.kc3 && Tt % 32 == 0 && !rows3_off)  // whole 32-row groups per slot: the bf16x3 kernel over the piece caches
+      ST_TRY(launch_attention_rows3(b.tq, b.kc3 + l * b.layer_stride3, b.vc3 + l * b.layer_stride3, b.row_pos, b.row_slot, R, Tt, HEADS,
+                                    cache_len, window, b.ta, st));
+    else
+      ST_TRY(launch_attention(b.tq, kc, vc, b.row_pos, b.row_slot, R, HEADS, HEADS, cache_len, window, b.ta, nullptr, st));
     {
       SmolttsGemmArgs a = mimi_gemm_f32(A + lw.wo, b.ta, D, R, D, D, lw.wo3 ? A + lw.wo3 : nullptr);
       a.epilogue = SMOLTTS_EPI_SCALE_RESID; a.scale_dev = (const float*)(A + lw.ls1);
@@ -284,7 +296,9 @@ int smoltts_mimi_session_create(SmolttsMimi* m, void* slab_dev, size_t slab_byte
   size_t total = 0;
   carve(s, (char*)slab_dev, &total);
   s->pos_host = static_cast<int*>(calloc((size_t)max_batch, sizeof(int)));
+  // (the piece caches are read in whole 32-position blocks: positions not written yet get zero weights and must hold finite values)
   if (s->pos_host == nullptr || hipMemset(s->zero_begin, 0, s->zero_bytes) != hipSuccess ||
+      (s->kc3 && (hipMemset(s->kc3, 0, s->kv3_layer * m->cfg.n_layers) != hipSuccess || hipMemset(s->vc3, 0, s->kv3_layer * m->cfg.n_layers) != hipSuccess)) ||
       hipMemcpy(&s->final_bias, m->arena + m->w.convs[NCONV - 1].b, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
     free(s->pos_host);
     delete s;
@@ -379,6 +393,7 @@ static int decode_chunk_impl(SmolttsMimiSession* s, const int32_t* codes_dev, in
     MimiTransformerBufs tb{s->tx, s->tn, s->tq, s->ta, s->th, s->kc, s->vc, (size_t)s->B * HEADS * c.max_positions * 64,
                            s->row_pos, s->row_slot};
     tb.tws = s->tws;
+    tb.kc3 = s->kc3; tb.vc3 = s->vc3; tb.layer_stride3 = s->kv3_layer;
     ST_TRY(run_mimi_transformer(A, m->w.layers, c.n_layers, (const float*)(A + m->w.rope), c.max_positions, c.window, tb, R, Tt,
                                 s->buf[0] + (size_t)BUF_HALO[0] * BUF_C[0], (int64_t)s->buf_bstride[0], st));
   }

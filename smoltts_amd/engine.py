@@ -58,7 +58,7 @@ class GemmArgs(C.Structure):
         ("row_pos_dev", C.c_void_p), ("row_slot_dev", C.c_void_p), ("k_cache_dev", C.c_void_p),
         ("v_cache_dev", C.c_void_p), ("n_q_heads", C.c_int32), ("n_kv_heads", C.c_int32), ("cache_len", C.c_int32),
         ("w3_dev", C.c_void_p), ("splitk_ws_dev", C.c_void_p), ("splitk_ws_floats", C.c_int64),
-        ("beta_dev", C.c_void_p), ("ln_scratch_dev", C.c_void_p),
+        ("beta_dev", C.c_void_p), ("ln_scratch_dev", C.c_void_p), ("k_cache3_dev", C.c_void_p), ("v_cache3_dev", C.c_void_p),
     ]
 
 
@@ -104,7 +104,7 @@ _EXPORTS = [
     "smoltts_mimi_slab_bytes", "smoltts_mimi_session_create", "smoltts_mimi_session_destroy", "smoltts_mimi_reset",
     "smoltts_mimi_decode_chunk", "smoltts_k_gemm", "smoltts_k_attention", "smoltts_k_embed", "smoltts_k_argmax",
     "smoltts_k_layernorm", "smoltts_k_gemm3", "smoltts_k_x3_pack",
-    "smoltts_session_measure_duplicate", "smoltts_session_margin_at", "smoltts_session_drop_graph", "smoltts_session_set_frames_per_graph", "smoltts_engine_fast_qkv_bytes", "smoltts_engine_build_fast_qkv", "smoltts_session_set_option", "smoltts_k_attention_split",
+    "smoltts_session_measure_duplicate", "smoltts_session_margin_at", "smoltts_session_drop_graph", "smoltts_session_set_frames_per_graph", "smoltts_engine_fast_qkv_bytes", "smoltts_engine_build_fast_qkv", "smoltts_session_set_option", "smoltts_k_attention_split", "smoltts_k_attention_rows3",
     "smoltts_session_slab_bytes_kv", "smoltts_session_create_kv", "smoltts_k_attention_kv", "smoltts_session_set_sampling", "smoltts_k_sample",
     "smoltts_lm_prefill_chunk", "smoltts_lm_prefill_deferred", "smoltts_mimi_reset_slots", "smoltts_mimi_encoder_create", "smoltts_mimi_encoder_destroy", "smoltts_mimi_encode_frames",
     "smoltts_mimi_encode_workspace_bytes", "smoltts_mimi_encode",
@@ -172,6 +172,7 @@ def load_library(path: Optional[Path] = None):
     lib.smoltts_engine_fast_qkv_bytes.restype = C.c_size_t
     lib.smoltts_engine_build_fast_qkv.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.smoltts_session_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.smoltts_k_attention_rows3.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p, C.c_void_p]
     lib.smoltts_k_attention_split.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.smoltts_mimi_reset_slots.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.smoltts_lm_prefill_deferred.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
@@ -190,7 +191,7 @@ def load_library(path: Optional[Path] = None):
     if hasattr(lib, "smoltts_profile_begin"):  # diagnostic builds only (-DSMOLTTS_DEBUG_HOOKS)
         lib.smoltts_profile_begin.argtypes = [C.c_int32] * 4
         lib.smoltts_profile_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
-    if lib.smoltts_abi_version() != 3:
+    if lib.smoltts_abi_version() != 4:
         raise SmolttsError("libsmoltts_hip.so ABI version mismatch")
     if path is None:
         _lib = lib

@@ -39,8 +39,10 @@ def linear(x: torch.Tensor, w_tiles: torch.Tensor, N: int, *, w_fp32: bool = Fal
            v_cache: Optional[torch.Tensor] = None, n_q_heads: int = 0, n_kv_heads: int = 0, cache_len: int = 0,
            elu_out: bool = False, raw_out: Optional[torch.Tensor] = None, raw_bstride: int = 0,
            w3: Optional[torch.Tensor] = None, splitk_ws: Optional[torch.Tensor] = None,
-           beta: Optional[torch.Tensor] = None, ln_scratch: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``w3`` (``pack_weight_w3`` of the same fp32 matrix): many-row calls run the bf16x3-split kernel (gemm_b3.hip)."""
+           beta: Optional[torch.Tensor] = None, ln_scratch: Optional[torch.Tensor] = None,
+           k_cache3: Optional[torch.Tensor] = None, v_cache3: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``w3`` (``pack_weight_w3`` of the same fp32 matrix): many-row calls run the bf16x3-split kernel (gemm_b3.hip).
+    ``k_cache3`` / ``v_cache3`` (``kv3_cache``): EPI_QKV_ROPE also writes the K / V rows as bf16x3 pieces (``attention_rows3``)."""
     lib = E.load_library()
     M = x.shape[0] if M is None else M
     K = x.shape[1] if K is None else K
@@ -64,6 +66,7 @@ def linear(x: torch.Tensor, w_tiles: torch.Tensor, N: int, *, w_fp32: bool = Fal
     a.w3_dev = E.dptr(w3)
     a.splitk_ws_dev, a.splitk_ws_floats = E.dptr(splitk_ws), (splitk_ws.numel() if splitk_ws is not None else 0)
     a.beta_dev, a.ln_scratch_dev = E.dptr(beta), E.dptr(ln_scratch)
+    a.k_cache3_dev, a.v_cache3_dev = E.dptr(k_cache3), E.dptr(v_cache3)
     E.check(lib.smoltts_k_gemm(C.byref(a), E.current_stream_ptr()), "smoltts_k_gemm")
     return out
 
@@ -78,6 +81,55 @@ def attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, row
     E.check(lib.smoltts_k_attention_kv(E.dptr(q), E.dptr(k_cache), E.dptr(v_cache), E.dptr(row_pos), E.dptr(row_slot),
                                        q.shape[0], n_q_heads, n_kv, cache_len, window, E.dptr(out), E.dptr(out_x3),
                                        1 if k_cache.dtype == torch.bfloat16 else 0, E.current_stream_ptr()), "smoltts_k_attention_kv")
+    return out
+
+
+def kv3_cache(slots: int, n_heads: int, cache_len: int, device="cuda") -> torch.Tensor:
+    """A zero-filled bf16x3 piece cache (include/smoltts_hip.h SMOLTTS_KV3_BYTES): uint8 [slots, heads, ceil32(cache_len) * 384]."""
+    return torch.zeros(slots, n_heads, (cache_len + 31) // 32 * 32 * 384, dtype=torch.uint8, device=device)
+
+
+def kv3_decode(cache3: torch.Tensor, cache_len: int, is_v: bool) -> torch.Tensor:
+    """The fp32 values [slots, heads, cache_len, 64] a piece cache holds (hi + mid + lo, summed smallest first: exact) -- tests."""
+    S, H = cache3.shape[0], cache3.shape[1]
+    cl = (cache_len + 31) // 32 * 32
+    raw = cache3.cpu().view(torch.bfloat16).float()  # [S, H, cl * 192]
+    if not is_v:  # [tile][chunk][piece][lane = 16 q + r][8]: K[16 tile + r][32 chunk + 8 q + j]
+        v = raw.view(S, H, cl // 16, 2, 3, 4, 16, 8)
+        v = (v[:, :, :, :, 2] + v[:, :, :, :, 1]) + v[:, :, :, :, 0]  # [S, H, tile, chunk, q, r, j]
+        return v.permute(0, 1, 2, 5, 3, 4, 6).reshape(S, H, cl, 64)[:, :, :cache_len].contiguous()
+    v = raw.view(S, H, cl // 32, 4, 3, 4, 16, 8)  # [pb][dim tile][piece][q][r][j]: V[32 pb + (j < 4 ? 4q + j : 16 + 4q + j - 4)][16 t + r]
+    v = (v[:, :, :, :, 2] + v[:, :, :, :, 1]) + v[:, :, :, :, 0]  # [S, H, pb, t, q, r, j]
+    v = v.view(S, H, cl // 32, 4, 4, 16, 2, 4)  # j = 4 * half + jj -> position 16 half + 4 q + jj
+    return v.permute(0, 1, 2, 6, 4, 7, 3, 5).reshape(S, H, cl, 64)[:, :, :cache_len].contiguous()
+
+
+def kv3_encode(values: torch.Tensor, is_v: bool) -> torch.Tensor:
+    """fp32 [slots, heads, cache_len, 64] -> the piece cache bytes (uint8 [slots, heads, ceil32(cache_len) * 384]); tests."""
+    S, H, L, _ = values.shape
+    cl = (L + 31) // 32 * 32
+    x = torch.zeros(S, H, cl, 64)
+    x[:, :, :L] = values.float().cpu()
+    hi = x.bfloat16()
+    r1 = x - hi.float()
+    mid = r1.bfloat16()
+    lo = (r1 - mid.float()).bfloat16()
+    pieces = torch.stack([hi, mid, lo], 0)  # [3, S, H, cl, 64]
+    if not is_v:  # -> [S, H, tile, chunk, piece, q, r, j]
+        v = pieces.view(3, S, H, cl // 16, 16, 2, 4, 8).permute(1, 2, 3, 5, 0, 6, 4, 7)
+    else:  # position = 32 pb + 16 half + 4 q + jj, dim = 16 t + r -> [S, H, pb, t, piece, q, r, half, jj]
+        v = pieces.view(3, S, H, cl // 32, 2, 4, 4, 4, 16).permute(1, 2, 3, 7, 0, 5, 8, 4, 6)
+    return v.contiguous().view(torch.uint8).reshape(S, H, cl * 384)
+
+
+def attention_rows3(q: torch.Tensor, k_cache3: torch.Tensor, v_cache3: torch.Tensor, row_pos: torch.Tensor, row_slot: torch.Tensor,
+                    rows_per_slot: int, n_heads: int, cache_len: int, window: int = 0) -> torch.Tensor:
+    """Attention of ``rows_per_slot`` (a multiple of 32) consecutive positions per slot over bf16x3 piece caches (attn_rows3_kernel)."""
+    lib = E.load_library()
+    out = torch.empty_like(q)
+    E.check(lib.smoltts_k_attention_rows3(E.dptr(q), E.dptr(k_cache3), E.dptr(v_cache3), E.dptr(row_pos), E.dptr(row_slot), q.shape[0],
+                                          rows_per_slot, n_heads, cache_len, window, E.dptr(out), E.current_stream_ptr()),
+            "smoltts_k_attention_rows3")
     return out
 
 
