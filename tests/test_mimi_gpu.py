@@ -208,3 +208,40 @@ def test_slots_stream_independently():
         ref = orc.decode(utt[b].T[None].long())[0, 0]
         assert got.shape == ref.shape and float((got - ref).pow(2).mean().sqrt()) < 1e-5, b
     sess.close(); eng.close()
+
+
+def test_mixed_chunk_sizes_share_the_piece_caches():
+    """Chunks of 3, 32, 5 and 16 frames in one stream: the 32- and 16-frame chunks (whole groups of 32 transformer rows per slot)
+    attend over the bf16x3 piece caches, the others over the fp32 caches -- every chunk's QKV GEMM writes both, so the history is
+    complete either way; a slot restarted mid-way finds its previous tenant's pieces masked.  Against the oracle's whole decode."""
+    from oracle.mimi_oracle import MimiDecodeOracle
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+    from smoltts_amd.engine import MimiEngine, MimiSession
+
+    st = synthetic_mimi_state(seed=4)
+    B, plan = 3, (3, 32, 5, 16, 32)
+    F = sum(plan)
+    eng = MimiEngine(st, 8, window=0, max_positions=2 * F + 16)
+    g = torch.Generator().manual_seed(9)
+    codes = torch.randint(0, 2048, (B, F, 8), generator=g, dtype=torch.int32)
+    second = torch.randint(0, 2048, (F, 8), generator=g, dtype=torch.int32)  # slot 1's second tenant, from the third chunk on
+    sess = MimiSession(eng, max_batch=B, max_chunk_frames=32)
+    sess.reset()
+    pcm = torch.empty(B, F * 1920, device="cuda")
+    grid = codes.clone()
+    f0 = 0
+    for i, n in enumerate(plan):
+        if i == 2:
+            sess.reset_slots([1])
+            grid[1, f0:] = second[: F - f0]
+            restart = f0
+        sess.decode_chunk(grid.cuda(), f0, n, pcm)
+        f0 += n
+    got = pcm.cpu().numpy()
+    orc = MimiDecodeOracle(st, window=0)
+    for b in (0, 2):
+        ref = orc.decode(codes[b:b + 1].permute(0, 2, 1).long())[0, 0].numpy()
+        assert _rms(got[b] - ref) <= RMS_TOL, b
+    ref1 = orc.decode(second[None, : F - restart].permute(0, 2, 1).long())[0, 0].numpy()
+    assert _rms(got[1, restart * 1920:] - ref1) <= RMS_TOL
+    sess.close(); eng.close()

@@ -15,7 +15,7 @@ for ln in open(sys.argv[1]):
     if "conv_xs_kernel<" in name and ", 2, 32, " in name:  # conv_xs.hip in Linear mode: the transformer's wqkv / wo
         grp = "transformer"
     elif "resblock" in name or "gemm_b3_kernel<4, 4, 0>" in name or "gemm_b3_kernel<4, 4, 1>" in name or "gemm_b3_kernel<2, 2, 0>" in name \
-            or "gemm_b3_kernel<2, 2, 1>" in name or "seanet" in name or "conv_xs" in name or "halo" in name or "rvq" in name:
+            or "gemm_b3_kernel<2, 2, 1>" in name or "seanet" in name or "conv_xs" in name or "conv_ks" in name or "halo" in name or "rvq" in name:
         grp = "seanet"
     elif "gemm_b3" in name or "attn" in name or "layernorm" in name or "splitk" in name or "mimi_rows" in name:
         grp = "transformer"
