@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SMOLTTS_ABI_VERSION 4
+#define SMOLTTS_ABI_VERSION 5
 
 enum {
   SMOLTTS_OK = 0,
@@ -208,10 +208,14 @@ int smoltts_session_set_frames_per_graph(SmolttsSession* s, int32_t n, void* str
  *                             launches of their own (default 1)
  *   SMOLTTS_OPT_SPLIT_ATTN    decode attention over the slow cache with the keys of a (row, kv head) pair on two workgroups,
  *                             merged in part order inside the launch (<= 128 pairs, i.e. B <= 32 at 4 kv heads; default 1).
- *                             fp32 sums in a different order than the one-workgroup kernel: same ids except at near-ties */
+ *                             fp32 sums in a different order than the one-workgroup kernel: same ids except at near-ties
+ *   SMOLTTS_OPT_FUSE_DEPTH_ATTN  (ABI 5) depth steps 1..: the attention over the <= 8-entry cache is worked out by the wo launch
+ *                             itself (SmolttsGemm3Args.attn_q_dev) instead of by a launch of its own (default 1; applies where
+ *                             smoltts_gemm3_attn_fusable); again another fp32 summation order than the stand-alone kernel */
 #define SMOLTTS_OPT_QKV_TABLE 1
 #define SMOLTTS_OPT_COMMIT_PICKS 2
 #define SMOLTTS_OPT_SPLIT_ATTN 3
+#define SMOLTTS_OPT_FUSE_DEPTH_ATTN 5
 #define SMOLTTS_OPT_STREAM_W 4  /* value = mask of SMOLTTS_STREAM_W_*: which weights of a decode frame are loaded with the non-temporal
                                   hint (read once per frame: keeping them out of the caches leaves room for the depth layers'
                                   weights, which are re-read for each of the 8 depth steps) */
@@ -463,7 +467,17 @@ typedef struct SmolttsGemm3Args {
   int32_t w_stream;            /* != 0: these weights are read once now and not again before the caches have turned over (the slow
                                   layers of a decode frame): their loads carry the non-temporal hint, so that they do not push the
                                   depth transformer's weights -- re-read 8 times per frame -- out of the Infinity Cache (M <= 128 only) */
+  /* EPI_RESID with the attention of a depth step as its activation operand (ABI 5): attn_q_dev != NULL means x3_dev is not read;
+   * instead every workgroup works out, for the rows it multiplies, softmax(q K^T / 8) V over keys 0 .. attn_pos of the row's own
+   * slot (row r == slot r) in k_cache_dev / v_cache_dev [M][n_kv_heads][cache_len][64] fp32 -- the output of
+   * smoltts_k_attention for those rows -- and feeds it to the matrix cores as bf16x3 pieces through LDS.  One launch instead of
+   * two per depth layer; needs smoltts_gemm3_attn_fusable(n_q_heads, n_kv_heads, cache_len) and K == n_q_heads * 64. */
+  const float* attn_q_dev;     /* fp32 [M][n_q_heads*64] (RoPE applied: the q rows an EPI_QKV_ROPE launch wrote) */
+  int32_t attn_pos;
 } SmolttsGemm3Args;
+
+/* 1 when the attention prologue above exists for this head layout (<= 12 query heads, groups of <= 4 per kv head, <= 8 cache entries) */
+int smoltts_gemm3_attn_fusable(int32_t n_q_heads, int32_t n_kv_heads, int32_t cache_len);
 
 int smoltts_k_gemm3(const SmolttsGemm3Args* a, void* stream);
 /* fp32 rows [n_rows][ldx] -> X3 operand(s) (+ sums of squares), for tests and operands without a fused producer */

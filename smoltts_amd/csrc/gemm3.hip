@@ -55,6 +55,8 @@ struct Gemm3Dev {
   int kv_bf16;
   char* v_x3;  // QKV_ROPE, rows at position 0: attention over one key is V itself -> V published as wo's X3 operand
   int n_q_heads, n_kv_heads, cache_len;
+  const float* aq;  // attn_wo_kernel: q rows [M][n_q_heads * 64] of the attention recomputed in front of the K loop ...
+  int a_pos;        // ... every row r being slot r at this position of the <= 8-entry caches kc / vc (a depth step)
   unsigned long long* stamps;  // diagnostics only (smoltts_debug_set_stamps); nullptr in production
 };
 
@@ -488,6 +490,268 @@ __global__ __launch_bounds__(256) void gemm3_rows_kernel(Gemm3Dev p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Depth-step attention recomputed in front of the output projection (round 4): x += Wo . attention(q, K, V) in ONE launch.
+//
+// The depth transformer's cache holds <= 8 keys (lm/generate.py:112: one per codebook step), so the attention of a row is
+// 12 heads x 8 keys x 64 dims -- small enough for every workgroup of the wo GEMM to work out the rows IT multiplies instead of
+// waiting for a launch of its own to publish them (28 launches per frame at 150m: every depth layer of steps 1..7).  No hand-off
+// between workgroups, no flag: the price is the q / K / V intake of the workgroup's rows and the redundant arithmetic, so the
+// decomposition keeps both small: a workgroup owns only R = 2 rows and, to keep the grid at one workgroup per CU, T = 3
+// adjacent 16-column weight tiles (150m, 32 rows: 16 x 16 = 256 workgroups).
+//
+//   phase A  one wave per (row, pair of kv heads): lane = 32 kq + 8 jj + m  (kq: kv head of the pair, jj = 0..3: key group,
+//            m = 0..7) holds dims [4m, 4m+4) and [32+4m, 32+4m+4) of its kv head's keys jj and jj + 4; the G query heads of the
+//            kv head share those registers.  Score = 8 FMAs + a 3-step DPP sum over the 8 lanes of a key; softmax per lane over
+//            its <= 2 keys, merged over the 4 key groups (row_ror:8, then lane ^ 16); the weighted V sums travel the same two
+//            steps, each lane handing over the half it does not publish.  Each lane ends up with 2 output values, splits them
+//            into bf16x3 and writes them to LDS in the MFMA B-fragment order of x3.h (R rows instead of 16 per chunk).
+//   phase B  the K loop of gemm3_kernel<1, T, 3, RESID> with the B fragments coming from LDS; same chunk -> wave deal, same
+//            fixed-order reduction, one finishing wave per column tile, same epilogue (residual, fp32 store, X3 emission,
+//            partial sums of squares).
+// Reference: Attention.forward (modeling/model/rq_transformer.py:535-570) at decode time inside forward_generate_fast
+// (mlx_inference/src/smoltts_mlx/lm/rq_transformer.py:194-220, 281-295).
+__device__ __forceinline__ float dpp_ror8(float x) {  // lane i of a 16-lane row <- lane i ^ 8
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row8_sum(float x) {  // sum over the 8 lanes of a half row, result in all of them
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  return x;
+}
+__device__ __forceinline__ float dot8(float4 a, float4 b, float4 k0, float4 k1) {
+  float d0 = a.x * k0.x, d1 = a.y * k0.y;  // two chains: the compiler packs them (v_pk_fma_f32)
+  d0 = fmaf(a.z, k0.z, d0); d1 = fmaf(a.w, k0.w, d1);
+  d0 = fmaf(b.x, k1.x, d0); d1 = fmaf(b.y, k1.y, d1);
+  d0 = fmaf(b.z, k1.z, d0); d1 = fmaf(b.w, k1.w, d1);
+  return d0 + d1;
+}
+
+constexpr int AWO_R = 2;  // rows per workgroup
+
+template <int G, int T, bool TWO, bool W8>  // TWO: more than 4 keys (a second key per lane)
+__global__ __launch_bounds__(512) void attn_wo_kernel(Gemm3Dev p) {
+  constexpr int WTILE = W8 ? 512 : 1024, WLANE = W8 ? 8 : 16;
+  constexpr int U = 3, R = AWO_R;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nwaves = blockDim.x >> 6;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int ng = blockIdx.x, row0 = blockIdx.y * R;
+  const int nchunks = p.K >> 5;
+  STAMP3(0);
+
+  // ---- phase A loads first (they are the critical path), then the weight stream, then the epilogue inputs
+  char* frag = reinterpret_cast<char*>(smem);  // [chunk][piece][q][row] x 16 B
+  const int L = p.a_pos + 1;                   // keys 0 .. a_pos
+  const int kq = lane >> 5, jj = (lane >> 3) & 3, hb = jj & 1, m8 = lane & 7;
+  const int HD = p.n_q_heads * 64;
+  const int kv_pairs = (p.n_kv_heads + 1) >> 1;
+  int n_units = (p.M - row0 < R ? p.M - row0 : R) * kv_pairs;  // (row, kv pair) units of this workgroup: units wave, wave + nwaves, ..
+  for (int unit = wave; unit < n_units; unit += nwaves) {
+    const int rl = unit / kv_pairs, kvh = (unit - rl * kv_pairs) * 2 + kq;
+    const int row = row0 + rl;  // == slot
+    const bool hv = kvh < p.n_kv_heads;
+    const int kvc = hv ? kvh : p.n_kv_heads - 1;
+    const long cb = (((long)row * p.n_kv_heads + kvc) * p.cache_len) * 64 + 4 * m8;
+    const bool ok0 = jj < L, ok1 = TWO && jj + 4 < L;
+    const long o0 = cb + (long)(ok0 ? jj : 0) * 64, o1 = cb + (long)(ok1 ? jj + 4 : 0) * 64;
+    // K: dims [4m, +4) and [32 + 4m, +4); V: the half this lane publishes (hb) first, the other half second
+    const float4 ka0 = *reinterpret_cast<const float4*>(p.kc + o0), kb0 = *reinterpret_cast<const float4*>(p.kc + o0 + 32);
+    const float4 va0 = *reinterpret_cast<const float4*>(p.vc + o0 + 32 * hb), vb0 = *reinterpret_cast<const float4*>(p.vc + o0 + 32 * (1 - hb));
+    float4 ka1, kb1, va1, vb1;
+    if (TWO) {
+      ka1 = *reinterpret_cast<const float4*>(p.kc + o1); kb1 = *reinterpret_cast<const float4*>(p.kc + o1 + 32);
+      va1 = *reinterpret_cast<const float4*>(p.vc + o1 + 32 * hb); vb1 = *reinterpret_cast<const float4*>(p.vc + o1 + 32 * (1 - hb));
+    }
+    float4 qa[G], qb[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float* qp = p.aq + (long)row * HD + (kvc * G + g) * 64 + 4 * m8;
+      qa[g] = *reinterpret_cast<const float4*>(qp);
+      qb[g] = *reinterpret_cast<const float4*>(qp + 32);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float4 a = make_float4(qa[g].x * 0.125f, qa[g].y * 0.125f, qa[g].z * 0.125f, qa[g].w * 0.125f);
+      const float4 b = make_float4(qb[g].x * 0.125f, qb[g].y * 0.125f, qb[g].z * 0.125f, qb[g].w * 0.125f);
+      float s0 = row8_sum(dot8(a, b, ka0, kb0)), s1 = -INFINITY;
+      s0 = ok0 ? s0 : -INFINITY;
+      if (TWO) {
+        s1 = row8_sum(dot8(a, b, ka1, kb1));
+        s1 = ok1 ? s1 : -INFINITY;
+      }
+      float mx = TWO ? fmaxf(s0, s1) : s0;
+      mx = fmaxf(mx, dpp_ror8(mx));
+      mx = fmaxf(mx, __shfl_xor(mx, 16));  // key 0 is always there: finite
+      const float e0 = __expf(s0 - mx);    // exp(-inf) = 0: keys behind the row's position drop out by themselves
+      float den = e0;
+      float4 oa = make_float4(e0 * va0.x, e0 * va0.y, e0 * va0.z, e0 * va0.w);
+      float4 ob = make_float4(e0 * vb0.x, e0 * vb0.y, e0 * vb0.z, e0 * vb0.w);
+      if (TWO) {
+        const float e1 = __expf(s1 - mx);
+        den += e1;
+        oa.x = fmaf(e1, va1.x, oa.x); oa.y = fmaf(e1, va1.y, oa.y); oa.z = fmaf(e1, va1.z, oa.z); oa.w = fmaf(e1, va1.w, oa.w);
+        ob.x = fmaf(e1, vb1.x, ob.x); ob.y = fmaf(e1, vb1.y, ob.y); ob.z = fmaf(e1, vb1.z, ob.z); ob.w = fmaf(e1, vb1.w, ob.w);
+      }
+      den += dpp_ror8(den);
+      den += __shfl_xor(den, 16);
+      // step 1 (lane ^ 8: the other half's publisher): hand over the sums of the half this lane does not publish
+      oa.x += dpp_ror8(ob.x); oa.y += dpp_ror8(ob.y); oa.z += dpp_ror8(ob.z); oa.w += dpp_ror8(ob.w);
+      // step 2 (lane ^ 16: same four values over the other two key groups): the lower lane publishes (x, y), the upper (z, w)
+      const bool up = (lane & 16) != 0;
+      const float t0 = __shfl_xor(up ? oa.x : oa.z, 16), t1 = __shfl_xor(up ? oa.y : oa.w, 16);
+      float inv = __builtin_amdgcn_rcpf(den);
+      inv = fmaf(fmaf(-den, inv, 1.0f), inv, inv);  // one Newton step: within an ulp of 1 / den
+      const float ox = ((up ? oa.z : oa.x) + t0) * inv, oy = ((up ? oa.w : oa.y) + t1) * inv;
+      uint32_t h, mm, l;
+      split3_pair(ox, oy, h, mm, l);
+      const int c = 2 * (kvc * G + g) + hb;  // chunk: head, half of its 64 dims
+      char* fp = frag + ((size_t)((c * 3) * 4 + (m8 >> 1)) * R + rl) * 16 + (m8 & 1) * 8 + (up ? 4 : 0);
+      if (hv) {
+        *reinterpret_cast<uint32_t*>(fp) = h;
+        *reinterpret_cast<uint32_t*>(fp + 4 * R * 16) = mm;
+        *reinterpret_cast<uint32_t*>(fp + 8 * R * 16) = l;
+      }
+    }
+  }
+
+  const char* wb[T];
+  bool wv[T];
+  uint4 wf[U][T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int ntile = ng * T + t;
+    wv[t] = ntile * 16 < p.N;
+    wb[t] = p.w + (size_t)ntile * nchunks * WTILE + lane * WLANE;
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int c = wave + u * nwaves;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      wf[u][t] = (c < nchunks && wv[t]) ? load_wfrag<W8, false>(wb[t] + (size_t)c * WTILE) : make_uint4(0, 0, 0, 0);
+  }
+
+  // epilogue inputs of the finishing waves (wave f: column tile f): in flight across the barrier and the K loop
+  const bool fin = wave < T;
+  const int tf = fin ? wave : 0;
+  const int m = row0 + r;
+  const bool row_on = r < R;
+  const bool mvalid = fin && row_on && m < p.M;
+  float4 rr, bb, ga, gb, ws;
+  rr = bb = make_float4(0.f, 0.f, 0.f, 0.f);
+  ga = gb = ws = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (fin) {
+    const int mc = m < p.M ? m : p.M - 1;
+    const int n0r = (ng * T + tf) * 16 + q * 4;
+    const int n0 = n0r < p.N ? n0r : p.N - 4;  // N % 4 == 0
+    if (W8) ws = *reinterpret_cast<const float4*>(p.wscale + n0);
+    rr = *reinterpret_cast<const float4*>(p.resid + (long)mc * p.ldo + n0);
+    if (p.bias != nullptr) bb = *reinterpret_cast<const float4*>(p.bias + n0);
+    if (p.emit.x3a && p.emit.gamma_a) ga = *reinterpret_cast<const float4*>(p.emit.gamma_a + n0);
+    if (p.emit.x3b && p.emit.gamma_b) gb = *reinterpret_cast<const float4*>(p.emit.gamma_b + n0);
+  }
+  STAMP3(5);
+  __syncthreads();
+
+  // ---- phase B: K loop, B fragments from LDS (lanes r >= R: zero columns)
+  f32x4 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int c = wave + u * nwaves;
+    if (c < nchunks) {  // wave-uniform
+      const char* fp = frag + ((size_t)((c * 3) * 4 + q) * R + (r & (R - 1))) * 16;
+      uint4 xb[3];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) xb[pc] = row_on ? *reinterpret_cast<const uint4*>(fp + pc * 4 * R * 16) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const bf16x8_t a = wfrag_bf16<W8>(wf[u][t]);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8_t, xb[pc]), acc[t], 0, 0, 0);
+      }
+    }
+  }
+  STAMP3(1);
+  float4* red4 = reinterpret_cast<float4*>(frag + (size_t)nchunks * 3 * 4 * R * 16);  // [wave][tile][lane]
+#pragma unroll
+  for (int t = 0; t < T; ++t) red4[(wave * T + t) * 64 + lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+  STAMP3(2);
+  __syncthreads();
+  STAMP3(3);
+  if (!fin) return;
+  {
+    float4 part[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) part[w] = red4[((w < nwaves ? w : 0) * T + tf) * 64 + lane];
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      const bool on = w < nwaves;
+      v[0] += on ? part[w].x : 0.f;
+      v[1] += on ? part[w].y : 0.f;
+      v[2] += on ? part[w].z : 0.f;
+      v[3] += on ? part[w].w : 0.f;
+    }
+    const int ntile = ng * T + tf;
+    const int n0 = ntile * 16 + q * 4;
+    const bool valid = mvalid && n0 < p.N;
+    if (W8) { v[0] *= ws.x; v[1] *= ws.y; v[2] *= ws.z; v[3] *= ws.w; }
+    v[0] = v[0] + bb.x + rr.x; v[1] = v[1] + bb.y + rr.y; v[2] = v[2] + bb.z + rr.z; v[3] = v[3] + bb.w + rr.w;
+    if (valid) {
+      *reinterpret_cast<float4*>(p.out + (long)m * p.ldo + n0) = make_float4(v[0], v[1], v[2], v[3]);
+      if (p.emit.x3a) x3_emit4(p.emit.x3a, m, n0, p.N >> 5, v[0] * ga.x, v[1] * ga.y, v[2] * ga.z, v[3] * ga.w);
+      if (p.emit.x3b) x3_emit4(p.emit.x3b, m, n0, p.N >> 5, v[0] * gb.x, v[1] * gb.y, v[2] * gb.z, v[3] * gb.w);
+    }
+    if (p.emit.ssq) {  // all 64 lanes take part in the shuffles
+      float sq = valid ? ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) : 0.f;
+      sq += __shfl_xor(sq, 16);
+      sq += __shfl_xor(sq, 32);
+      if (q == 0 && mvalid && ntile * 16 < p.N) p.emit.ssq[(size_t)m * (p.N >> 4) + ntile] = sq;
+    }
+  }
+  STAMP3(4);
+}
+
+template <int G, bool W8>
+static int launch_attn_wo_g(const Gemm3Dev& d, hipStream_t stream) {
+  const int nchunks = d.K / 32, ntiles = (d.N + 15) / 16;
+  int nwaves = (nchunks + 2) / 3;
+  nwaves = nwaves < 1 ? 1 : (nwaves > 8 ? 8 : nwaves);  // the K split of launch3_fmt (chunks w, w + nwaves, w + 2 nwaves per wave)
+  // few rows: one column tile per workgroup so that the weight stream is spread over the chip; many: three (<= one workgroup per
+  // CU at 32 rows x 48 tiles)
+  const int T = d.M > 16 ? 3 : 1;
+  if (nwaves < T) nwaves = T;
+  const dim3 grid((ntiles + T - 1) / T, (d.M + AWO_R - 1) / AWO_R);
+  ST_REQUIRE(grid.y <= 65535, SMOLTTS_E_INVALID, "gemm3: M=%d too large for one launch", d.M);
+  const size_t lds = (size_t)nchunks * 3 * 4 * AWO_R * 16 + (size_t)nwaves * T * 1024;
+  const bool two = d.a_pos + 1 > 4;
+  if (T == 3) {
+    if (two) hipLaunchKernelGGL((attn_wo_kernel<G, 3, true, W8>), grid, dim3(nwaves * 64), lds, stream, d);
+    else hipLaunchKernelGGL((attn_wo_kernel<G, 3, false, W8>), grid, dim3(nwaves * 64), lds, stream, d);
+  } else {
+    if (two) hipLaunchKernelGGL((attn_wo_kernel<G, 1, true, W8>), grid, dim3(nwaves * 64), lds, stream, d);
+    else hipLaunchKernelGGL((attn_wo_kernel<G, 1, false, W8>), grid, dim3(nwaves * 64), lds, stream, d);
+  }
+  ST_CHECK_HIP(hipGetLastError());
+  return SMOLTTS_OK;
+}
+
+template <bool W8>
+static int launch_attn_wo(const Gemm3Dev& d, hipStream_t stream) {
+  switch (d.n_q_heads / d.n_kv_heads) {
+    case 1: return launch_attn_wo_g<1, W8>(d, stream);
+    case 2: return launch_attn_wo_g<2, W8>(d, stream);
+    case 3: return launch_attn_wo_g<3, W8>(d, stream);
+    default: return launch_attn_wo_g<4, W8>(d, stream);
+  }
+}
+
 template <int EPI, bool W8>
 static int launch3_rows(const Gemm3Dev& d, hipStream_t stream) {
   const int ntiles = (d.N + 15) / 16;
@@ -574,7 +838,7 @@ int launch_gemm3(const SmolttsGemm3Args& a, hipStream_t stream) {
 static int launch_gemm3_impl(const SmolttsGemm3Args& a, hipStream_t stream) {
   ST_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 32 == 0 && a.N % 4 == 0, SMOLTTS_E_INVALID,
              "gemm3: bad shape M=%d N=%d K=%d (K %% 32, N %% 4)", a.M, a.N, a.K);
-  ST_REQUIRE(a.w_dev && a.x3_dev, SMOLTTS_E_INVALID, "gemm3: null operand");
+  ST_REQUIRE(a.w_dev && (a.x3_dev || (a.attn_q_dev && a.epilogue == SMOLTTS_EPI_RESID)), SMOLTTS_E_INVALID, "gemm3: null operand");
   ST_REQUIRE(a.ssq_in_dev == nullptr || a.K % 64 == 0, SMOLTTS_E_INVALID, "gemm3: normed input needs K %% 64 == 0");
   Gemm3Dev d;
   memset(&d, 0, sizeof(d));
@@ -601,6 +865,15 @@ static int launch_gemm3_impl(const SmolttsGemm3Args& a, hipStream_t stream) {
     case SMOLTTS_EPI_RESID:
       ST_REQUIRE(a.out_dev && a.resid_dev && a.ldo % 4 == 0, SMOLTTS_E_INVALID, "gemm3: RESID needs out/resid/ldo");
       ST_REQUIRE(!(a.emit_a_dev || a.emit_b_dev || a.ssq_out_dev) || a.N % 64 == 0, SMOLTTS_E_INVALID, "gemm3: emission needs N %% 64 == 0");
+      if (a.attn_q_dev) {  // the activation operand is the depth-step attention of these rows, worked out inside the launch
+        ST_REQUIRE(smoltts_gemm3_attn_fusable(a.n_q_heads, a.n_kv_heads, a.cache_len) && a.K == a.n_q_heads * 64 && a.k_cache_dev && a.v_cache_dev &&
+                       a.kv_format == SMOLTTS_KV_F32 && a.attn_pos >= 0 && a.attn_pos < a.cache_len && !a.ssq_in_dev,
+                   SMOLTTS_E_INVALID, "gemm3: attention prologue needs <= 12 query heads in groups of <= 4, <= 8 cache entries (fp32), "
+                   "K = heads * 64 and 0 <= attn_pos < cache_len (heads %d/%d, cache_len %d, K %d, attn_pos %d)", a.n_q_heads, a.n_kv_heads,
+                   a.cache_len, a.K, a.attn_pos);
+        d.aq = a.attn_q_dev; d.a_pos = a.attn_pos;
+        return d.wscale ? launch_attn_wo<true>(d, stream) : launch_attn_wo<false>(d, stream);
+      }
       return launch3_epi<SMOLTTS_EPI_RESID>(d, stream);
     case SMOLTTS_EPI_SWIGLU:
       ST_REQUIRE(a.x3_out_dev && a.N % 64 == 0, SMOLTTS_E_INVALID, "gemm3: SWIGLU needs x3_out and N %% 64 == 0");
@@ -642,6 +915,10 @@ int launch_x3_pack(const float* x, int64_t ldx, int n_rows, int dim, void* x3a, 
 }  // namespace smoltts
 
 extern "C" {
+int smoltts_gemm3_attn_fusable(int32_t n_q_heads, int32_t n_kv_heads, int32_t cache_len) {
+  return n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0 && n_q_heads / n_kv_heads <= 4 && n_q_heads <= 12 &&
+         cache_len > 0 && cache_len <= 8;
+}
 int smoltts_k_gemm3(const SmolttsGemm3Args* a, void* stream) {
   using namespace smoltts;
   ST_REQUIRE(a, SMOLTTS_E_INVALID, "k_gemm3: null args");

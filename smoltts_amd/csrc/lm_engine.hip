@@ -91,6 +91,7 @@ struct SmolttsSession {
   bool commit_picks;           // slow token and last depth code picked inside the commit kernel (SMOLTTS_OPT_COMMIT_PICKS)
   bool split_attn;             // slow attention of few rows over two workgroups per (row, kv head) (SMOLTTS_OPT_SPLIT_ATTN)
   int stream_w;                // which weights of a decode frame are loaded with the non-temporal hint (SMOLTTS_OPT_STREAM_W, bit mask)
+  bool fuse_depth_attn;        // depth attention worked out inside the wo launch (SMOLTTS_OPT_FUSE_DEPTH_ATTN)
 };
 
 namespace {
@@ -315,7 +316,11 @@ int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, i
     if (first_pos) a.v_x3_dev = s->x3a;
     ST_TRY(launch_gemm3_m(s, a, st));
   }
-  if (!first_pos) {
+  // depth steps 1..: the <= 8-key attention is recomputed by every workgroup of the wo launch for its own rows (gemm3.hip
+  // attn_wo_kernel): one launch less per layer
+  const bool fused_attn = !first_pos && iota_pos > 0 && s->fuse_depth_attn && kv_format == SMOLTTS_KV_F32 &&
+                          smoltts_gemm3_attn_fusable(n_head, n_kv, cache_len) && dim == n_head * 64;
+  if (!first_pos && !fused_attn) {
     const int reps = dup_hit(s, cache_len <= 16 ? 100 : 101, 0) ? 2 : 1;
     for (int i = 0; i < reps; ++i)
       ST_TRY(launch_attention(q, kc, vc, row_pos, row_slot, M, n_head, n_kv, cache_len, 0, nullptr, s->x3a, st, kv_format, iota_pos,
@@ -325,6 +330,10 @@ int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, i
     SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.wo, s->x3a, M, dim, dim, SMOLTTS_EPI_RESID);
     a.resid_dev = x; a.out_dev = x; a.ldo = dim;
     a.emit_a_dev = s->x3n; a.gamma_a_dev = (const float*)(A + bw.ffn_norm); a.ssq_out_dev = s->ssq; a.w_stream = (w_stream & (1 | SMOLTTS_STREAM_W_DEPTH_QKVO)) != 0;
+    if (fused_attn) {
+      a.attn_q_dev = q; a.attn_pos = iota_pos; a.k_cache_dev = (float*)kc; a.v_cache_dev = (float*)vc;
+      a.n_q_heads = n_head; a.n_kv_heads = n_kv; a.cache_len = cache_len; a.kv_format = SMOLTTS_KV_F32;
+    }
     ST_TRY(launch_gemm3(a, st));
   }
   {  // h = silu(w1 n) * (w3 n), n = RMSNorm(x); written as w2's operand
@@ -735,6 +744,7 @@ int smoltts_session_create_kv(SmolttsEngine* e, void* slab_dev, size_t slab_byte
   s->commit_picks = true;
   s->split_attn = true;
   s->stream_w = SMOLTTS_STREAM_W_DEFAULT;
+  s->fuse_depth_attn = true;
   s->kv_format = kv_format;
   size_t total = 0;
   carve(s, (char*)slab_dev, &total);
@@ -965,6 +975,7 @@ int smoltts_session_set_option(SmolttsSession* s, int32_t option, int32_t value)
     case SMOLTTS_OPT_COMMIT_PICKS: s->commit_picks = value != 0; break;
     case SMOLTTS_OPT_SPLIT_ATTN: s->split_attn = value != 0; break;
     case SMOLTTS_OPT_STREAM_W: s->stream_w = value; break;
+    case SMOLTTS_OPT_FUSE_DEPTH_ATTN: s->fuse_depth_attn = value != 0; break;
     default:
       set_error("session_set_option: unknown option %d", option);
       return SMOLTTS_E_INVALID;

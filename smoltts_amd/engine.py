@@ -104,7 +104,7 @@ _EXPORTS = [
     "smoltts_mimi_slab_bytes", "smoltts_mimi_session_create", "smoltts_mimi_session_destroy", "smoltts_mimi_reset",
     "smoltts_mimi_decode_chunk", "smoltts_k_gemm", "smoltts_k_attention", "smoltts_k_embed", "smoltts_k_argmax",
     "smoltts_k_layernorm", "smoltts_k_gemm3", "smoltts_k_x3_pack",
-    "smoltts_session_measure_duplicate", "smoltts_session_margin_at", "smoltts_session_drop_graph", "smoltts_session_set_frames_per_graph", "smoltts_engine_fast_qkv_bytes", "smoltts_engine_build_fast_qkv", "smoltts_session_set_option", "smoltts_k_attention_split", "smoltts_k_attention_rows3",
+    "smoltts_session_measure_duplicate", "smoltts_session_margin_at", "smoltts_session_drop_graph", "smoltts_session_set_frames_per_graph", "smoltts_engine_fast_qkv_bytes", "smoltts_engine_build_fast_qkv", "smoltts_session_set_option", "smoltts_gemm3_attn_fusable", "smoltts_k_attention_split", "smoltts_k_attention_rows3",
     "smoltts_session_slab_bytes_kv", "smoltts_session_create_kv", "smoltts_k_attention_kv", "smoltts_session_set_sampling", "smoltts_k_sample",
     "smoltts_lm_prefill_chunk", "smoltts_lm_prefill_deferred", "smoltts_mimi_reset_slots", "smoltts_mimi_encoder_create", "smoltts_mimi_encoder_destroy", "smoltts_mimi_encode_frames",
     "smoltts_mimi_encode_workspace_bytes", "smoltts_mimi_encode",
@@ -191,7 +191,7 @@ def load_library(path: Optional[Path] = None):
     if hasattr(lib, "smoltts_profile_begin"):  # diagnostic builds only (-DSMOLTTS_DEBUG_HOOKS)
         lib.smoltts_profile_begin.argtypes = [C.c_int32] * 4
         lib.smoltts_profile_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
-    if lib.smoltts_abi_version() != 4:
+    if lib.smoltts_abi_version() != 5:
         raise SmolttsError("libsmoltts_hip.so ABI version mismatch")
     if path is None:
         _lib = lib
@@ -292,7 +292,7 @@ def _fill_block(dst: BlockWeights, src: Dict[str, int]) -> None:
         setattr(dst, k, v)
 
 
-OPT_QKV_TABLE, OPT_COMMIT_PICKS, OPT_SPLIT_ATTN, OPT_STREAM_W = 1, 2, 3, 4  # include/smoltts_hip.h SMOLTTS_OPT_*
+OPT_QKV_TABLE, OPT_COMMIT_PICKS, OPT_SPLIT_ATTN, OPT_STREAM_W, OPT_FUSE_DEPTH_ATTN = 1, 2, 3, 4, 5  # include/smoltts_hip.h SMOLTTS_OPT_*
 
 
 class LMEngine:
@@ -403,6 +403,8 @@ class LMSession:
             self.use_commit_picks(False)
         if os.environ.get("SMOLTTS_SPLIT_ATTN") == "0":
             self.use_split_attention(False)
+        if os.environ.get("SMOLTTS_FUSE_DEPTH_ATTN") == "0":
+            self.use_fused_depth_attention(False)
         if os.environ.get("SMOLTTS_STREAM_W") is not None:  # mask of SMOLTTS_STREAM_W_* bits
             check(self.lib.smoltts_session_set_option(self.handle, OPT_STREAM_W, int(os.environ["SMOLTTS_STREAM_W"])), "smoltts_session_set_option")
 
@@ -489,6 +491,10 @@ class LMSession:
     def use_split_attention(self, on: bool) -> None:
         """Slow attention of few rows with the keys of a (row, kv head) pair on two workgroups (default) or on one."""
         check(self.lib.smoltts_session_set_option(self.handle, OPT_SPLIT_ATTN, 1 if on else 0), "smoltts_session_set_option")
+
+    def use_fused_depth_attention(self, on: bool) -> None:
+        """Depth steps 1..: attention over the <= 8-entry cache inside the wo launch (default) or as a launch of its own."""
+        check(self.lib.smoltts_session_set_option(self.handle, OPT_FUSE_DEPTH_ATTN, 1 if on else 0), "smoltts_session_set_option")
 
     def use_commit_picks(self, on: bool) -> None:
         """The frame's slow token and last depth code picked inside the commit kernel (default) or in launches of their own."""

@@ -222,6 +222,7 @@ class Gemm3Args(C.Structure):
         ("cache_len", C.c_int32), ("w_format", C.c_int32), ("w_scale_dev", C.c_void_p), ("v_x3_dev", C.c_void_p),
         ("kv_format", C.c_int32),
         ("w_stream", C.c_int32),
+        ("attn_q_dev", C.c_void_p), ("attn_pos", C.c_int32),
     ]
 
 
@@ -240,14 +241,17 @@ def linear3(x3: torch.Tensor, w_tiles: torch.Tensor, M: int, N: int, K: int, *, 
             emit_b: Optional[torch.Tensor] = None, gamma_b: Optional[torch.Tensor] = None,
             ssq_out: Optional[torch.Tensor] = None, rope=None, row_pos=None, row_slot=None, k_cache=None, v_cache=None,
             n_q_heads: int = 0, n_kv_heads: int = 0, cache_len: int = 0, w_scale: Optional[torch.Tensor] = None,
-            v_x3: Optional[torch.Tensor] = None, kv_format: int = 0, w_stream: bool = False):
+            v_x3: Optional[torch.Tensor] = None, kv_format: int = 0, w_stream: bool = False,
+            attn_q: Optional[torch.Tensor] = None, attn_pos: int = 0):
     """The bf16-MFMA GEMM over an X3 operand; returns the fp32 ``out`` tensor (None for SWIGLU).
-    ``w_scale`` given: ``w_tiles`` are e4m3 tiles (``pack_weight_fp8``)."""
+    ``w_scale`` given: ``w_tiles`` are e4m3 tiles (``pack_weight_fp8``).
+    ``attn_q`` given (EPI_RESID): ``x3`` may be None -- the operand is the attention of ``attn_q`` over keys 0..``attn_pos`` of
+    ``k_cache`` / ``v_cache`` (row r = slot r), worked out inside the launch (attn_wo_kernel)."""
     lib = E.load_library()
     lib.smoltts_k_gemm3.argtypes = [C.POINTER(Gemm3Args), C.c_void_p]
     if out is None and epilogue != E.EPI_SWIGLU:
         cols = n_q_heads * 64 if epilogue == E.EPI_QKV_ROPE else N
-        out = torch.zeros(M, cols, dtype=torch.float32, device=x3.device)
+        out = torch.zeros(M, cols, dtype=torch.float32, device=w_tiles.device)
     a = Gemm3Args()
     a.w_dev, a.x3_dev, a.M, a.N, a.K, a.epilogue = E.dptr(w_tiles), E.dptr(x3), M, N, K, epilogue
     a.ssq_in_dev, a.eps, a.bias_dev, a.resid_dev = E.dptr(ssq_in), eps, E.dptr(bias), E.dptr(resid)
@@ -263,5 +267,6 @@ def linear3(x3: torch.Tensor, w_tiles: torch.Tensor, M: int, N: int, K: int, *, 
     a.v_x3_dev = E.dptr(v_x3)
     a.kv_format = int(kv_format)
     a.w_stream = 1 if w_stream else 0
+    a.attn_q_dev, a.attn_pos = E.dptr(attn_q), int(attn_pos)
     E.check(lib.smoltts_k_gemm3(C.byref(a), E.current_stream_ptr()), "smoltts_k_gemm3")
     return out

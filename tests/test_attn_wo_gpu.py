@@ -1,0 +1,171 @@
+"""Depth-step attention worked out inside the output projection's launch (gemm3.hip attn_wo_kernel, SmolttsGemm3Args.attn_q_dev)
+against fp32 PyTorch on the CPU and against the two launches it replaces (smoltts_k_attention -> smoltts_k_gemm3).
+
+Reference arithmetic: Attention.forward at decode time (modeling/model/rq_transformer.py:535-570: softmax(q K^T / 8) V with the
+kv heads repeated for their query heads, then wo) inside forward_generate_fast (mlx_inference/src/smoltts_mlx/lm/rq_transformer.py
+:194-220) + the residual add of the block (:266-295).  The fused launch sums in another fp32 order than the stand-alone kernels,
+so it is compared with a tolerance; the engine-level test then requires the same ids from both launch structures."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    from smoltts_amd import engine
+
+    engine.load_library()
+    return engine
+
+
+@pytest.fixture(scope="module")
+def ops(E):
+    from smoltts_amd import ops
+
+    return ops
+
+
+def bf16r(t):
+    return t.to(torch.bfloat16).float()
+
+
+def rel_err(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def attention_ref(q, kc, vc, pos, Hq):
+    """q [M, Hq*64]; caches [M, KV, L, 64]; keys 0..pos of the row's own slot."""
+    M, KV = q.shape[0], kc.shape[1]
+    G = Hq // KV
+    qh = q.view(M, Hq, 64).double()
+    k = kc[:, :, : pos + 1].double().repeat_interleave(G, dim=1)  # [M, Hq, L, 64]
+    v = vc[:, :, : pos + 1].double().repeat_interleave(G, dim=1)
+    s = torch.einsum("mhd,mhjd->mhj", qh, k) / 8.0
+    p = torch.softmax(s, dim=-1)
+    return torch.einsum("mhj,mhjd->mhd", p, v).reshape(M, Hq * 64).float()
+
+
+# (rows, query heads, kv heads): the 150m / 70m / tiny / tiny_proj depth transformers, a G = 4 and a G = 1 layout, ragged row counts
+SHAPES = [(32, 12, 4), (32, 9, 3), (5, 6, 2), (1, 2, 1), (19, 8, 2), (64, 12, 4), (9, 5, 5), (33, 12, 4)]
+
+
+@pytest.mark.parametrize("M,Hq,KV", SHAPES)
+@pytest.mark.parametrize("pos", [0, 1, 2, 4, 7])
+def test_attn_wo_against_torch_and_the_two_launches(E, ops, M, Hq, KV, pos):
+    assert E.load_library().smoltts_gemm3_attn_fusable(Hq, KV, 8) == 1
+    g = torch.Generator().manual_seed(M * 131 + Hq * 7 + pos)
+    K = N = Hq * 64
+    q = torch.randn(M, K, generator=g) * 1.5
+    kc = torch.randn(M, KV, 8, 64, generator=g)
+    vc = torch.randn(M, KV, 8, 64, generator=g)
+    kc[:, :, pos + 1:] = float("nan")  # entries behind the row's position must never be read into a result
+    vc[:, :, pos + 1:] = float("nan")
+    w = bf16r(torch.randn(N, K, generator=g) * 0.04)
+    r = torch.randn(M, N, generator=g)
+    ga = 1 + 0.1 * torch.randn(N, generator=g)
+    att = attention_ref(q, kc, vc, pos, Hq)
+    ref = r + att @ w.T
+    wt = ops.pack_weight(w)
+    qd, kd, vd = q.cuda(), kc.cuda(), vc.cuda()
+
+    # fused: one launch
+    rd = r.cuda()
+    ea = ops.x3_alloc(M, N)
+    ssq = torch.zeros(M, N // 16).cuda()
+    ops.linear3(None, wt, M, N, K, epilogue=E.EPI_RESID, resid=rd, out=rd, emit_a=ea, gamma_a=ga.cuda(), ssq_out=ssq,
+                attn_q=qd, attn_pos=pos, k_cache=kd, v_cache=vd, n_q_heads=Hq, n_kv_heads=KV, cache_len=8)
+    out = rd.cpu()
+    assert torch.isfinite(out).all()
+    assert rel_err(out, ref) < 2e-5
+    assert rel_err(ops.x3_to_float(ea, M, N), out * ga) < 1e-6
+    assert torch.allclose(ssq.cpu().sum(-1), (out * out).sum(-1), rtol=1e-5)
+
+    # the two launches it replaces
+    row_pos = torch.full((M,), pos, dtype=torch.int32).cuda()
+    row_slot = torch.arange(M, dtype=torch.int32).cuda()
+    ax3 = ops.x3_alloc(M, K)
+    a2 = ops.attention(qd, kd, vd, row_pos, row_slot, Hq, out_x3=ax3)
+    assert rel_err(a2.cpu(), att) < 2e-6
+    rd2 = r.cuda()
+    ops.linear3(ax3, wt, M, N, K, epilogue=E.EPI_RESID, resid=rd2, out=rd2)
+    assert rel_err(out, rd2.cpu()) < 5e-6
+
+
+def test_attn_wo_fp8_weights(E, ops):
+    M, Hq, KV, pos = 32, 12, 4, 5
+    g = torch.Generator().manual_seed(99)
+    K = N = Hq * 64
+    q = torch.randn(M, K, generator=g)
+    kc, vc = torch.randn(M, KV, 8, 64, generator=g), torch.randn(M, KV, 8, 64, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.04
+    r = torch.randn(M, N, generator=g)
+    wt, scale, wdq = ops.pack_weight_fp8(w)
+    ref = r + attention_ref(q, kc, vc, pos, Hq) @ wdq.T
+    rd = r.cuda()
+    ops.linear3(None, wt, M, N, K, epilogue=E.EPI_RESID, resid=rd, out=rd, w_scale=scale, attn_q=q.cuda(), attn_pos=pos,
+                k_cache=kc.cuda(), v_cache=vc.cuda(), n_q_heads=Hq, n_kv_heads=KV, cache_len=8)
+    assert rel_err(rd.cpu(), ref) < 2e-5
+
+
+def test_attn_wo_refuses_what_it_cannot_do(E, ops):
+    lib = E.load_library()
+    assert lib.smoltts_gemm3_attn_fusable(16, 4, 8) == 0   # K = 1024 > 768
+    assert lib.smoltts_gemm3_attn_fusable(12, 4, 16) == 0  # more than 8 cache entries
+    assert lib.smoltts_gemm3_attn_fusable(10, 2, 8) == 0   # groups of 5
+    M, Hq, KV = 4, 12, 4
+    K = N = 768
+    z = torch.zeros(M, K).cuda()
+    c = torch.zeros(M, KV, 8, 64).cuda()
+    wt = ops.pack_weight(torch.zeros(N, K))
+    with pytest.raises(E.SmolttsError):  # position outside the cache
+        ops.linear3(None, wt, M, N, K, epilogue=E.EPI_RESID, resid=z, out=z, attn_q=z, attn_pos=8, k_cache=c, v_cache=c,
+                    n_q_heads=Hq, n_kv_heads=KV, cache_len=8)
+    with pytest.raises(E.SmolttsError):  # K is not heads * 64
+        ops.linear3(None, wt, M, N, K, epilogue=E.EPI_RESID, resid=z, out=z, attn_q=z, attn_pos=1, k_cache=c, v_cache=c,
+                    n_q_heads=6, n_kv_heads=2, cache_len=8)
+
+
+def _prompts(cfg, tok, tc, texts):
+    from smoltts_amd.prompt import PromptEncoder
+
+    pe = PromptEncoder(tok, tc.semantic_start_id, cfg.num_codebooks, cfg.duplicate_code_0)
+    return [pe.build_prompt(t, v) for t, v in texts]
+
+
+TEXTS = [("the quick brown fox", "heart"), ("jumps over", "nova"), ("a lazy dog, twice; and then once more", "sky"),
+         ("0123456789", "bella"), ("z", "liam"), ("fused or not, the ids are the same", "emma")]
+
+
+@pytest.mark.parametrize("name,fmt", [("tiny", "bf16"), ("tiny_nodup", "bf16"), ("tiny_proj", "bf16"), ("smoltts_byte_70m", "bf16"),
+                                      ("smoltts_byte_150m", "bf16"), ("tiny", "fp8")])
+def test_fused_and_unfused_frames_emit_the_same_ids(name, fmt):
+    from smoltts_amd.config import TokenConfig
+    from smoltts_amd.engine import LMEngine, LMSession
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+    from smoltts_amd.tokenizer import load_tokenizer
+
+    cfg = named_config(name)
+    tok = load_tokenizer()
+    tc = TokenConfig.from_tokenizer(tok, cfg)
+    eng = LMEngine(cfg, synthetic_lm_state(cfg, seed=11), tc, weight_format=fmt)
+    prompts = _prompts(cfg, tok, tc, TEXTS)
+    F = 12
+    out = {}
+    for fused in (True, False):
+        for table in (True, False):
+            s = LMSession(eng, max_batch=len(prompts), max_seq=256, max_rows=512, max_frames=F)
+            s.use_fused_depth_attention(fused)
+            s.use_qkv_table(table)
+            s.prefill(prompts, stop_on_eos=False)
+            s.decode(F - 1)
+            codes, n, _, margin = s.fetch()
+            assert (n == F).all()
+            out[fused, table] = (codes[:, :F].copy(), margin.copy())
+            s.close()
+    base = out[False, False]
+    for key, got in out.items():
+        assert np.array_equal(got[0], base[0]), f"ids differ between launch structures {key} and (False, False)"
+        assert np.allclose(got[1], base[1], rtol=2e-2, atol=2e-6)  # the smallest top-2 gaps agree (other summation order)
+    eng.close()
