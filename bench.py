@@ -37,7 +37,7 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("TORCH_COMPILE_DISABLE", "1")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-PROFILE_TAG = "r03"    # profiles/<tag>_* hold the rocprofv3 summaries of this round
+PROFILE_TAG = "r04"    # profiles/<tag>_* hold the rocprofv3 summaries of this round
 
 _T0 = time.perf_counter()
 
@@ -98,8 +98,9 @@ def parse_args(argv=None):
 
 
 # ------------------------------------------------------------------------------------------- launcher
-def _launch_once(n: int, argv, pin: bool):
-    """One attempt of the parent of an N-rank run (-> (exit code, seconds it took, did rank 0 print its line)): spawn one child per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
+def _launch_once(n: int, argv, pin: bool, extra_env=None):
+    """One attempt of the parent of an N-rank run (-> (exit code, seconds it took, did rank 0 print its line, the rank that failed
+    first or -1); a rank killed by a signal has a NEGATIVE code, as subprocess reports it): spawn one child per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
     torch.distributed.run sets them), relay rank 0's stdout, return the first non-zero exit code (0 if none).  This
     process makes no GPU call (it does not even import torch).  Every child runs in a session of its own and sees exactly
     one GPU (HIP_VISIBLE_DEVICES = its entry of the parent's device list, set before the child's first GPU call;
@@ -119,8 +120,9 @@ def _launch_once(n: int, argv, pin: bool):
     visible = [d for d in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if d.strip()] or [str(i) for i in range(n)]
     if pin and len(visible) < n:
         print(f"[bench launcher] HIP_VISIBLE_DEVICES lists {len(visible)} devices for {n} ranks", file=sys.stderr, flush=True)
-        return 2, 0.0, False
+        return 2, 0.0, False, -1
     procs = []
+    failed_rank = -1
 
     def stop_children(grace=15.0):
         live = [p for p in procs if p.poll() is None]
@@ -147,6 +149,7 @@ def _launch_once(n: int, argv, pin: bool):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+            env.update(extra_env or {})
             if pin:
                 env["HIP_VISIBLE_DEVICES"] = visible[r]
                 env["SMOLTTS_BENCH_PINNED"] = "1"  # the rank's one visible GPU is device 0
@@ -172,7 +175,7 @@ def _launch_once(n: int, argv, pin: bool):
                 if code is not None:
                     live.discard(r)
                     if code != 0:
-                        rc = code
+                        rc, failed_rank = code, r
                         print(f"[bench launcher] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr, flush=True)
         if got_signal:
             rc = 128 + got_signal[0]
@@ -183,7 +186,7 @@ def _launch_once(n: int, argv, pin: bool):
             signal.signal(sig, h)
         if t is not None:
             t.join(timeout=5)
-    return rc, time.time() - t_start, bool(printed)
+    return rc, time.time() - t_start, bool(printed), failed_rank
 
 
 def self_launch(n: int, argv) -> int:
@@ -192,12 +195,25 @@ def self_launch(n: int, argv) -> int:
     per-process device masks shows at the rendezvous / weight broadcast, in the first seconds), ONE second attempt runs with
     the binding left to LOCAL_RANK -> torch.cuda.set_device, as under torch.distributed.run -- said loudly on stderr."""
     pin = os.environ.get("SMOLTTS_BENCH_PIN_DEVICES", "1") != "0" and os.environ.get("SMOLTTS_BENCH_ONE_DEVICE") != "1"
-    rc, took, printed = _launch_once(n, argv, pin)
-    if rc != 0 and rc < 128 and pin and not printed and os.environ.get("SMOLTTS_BENCH_NO_FALLBACK") != "1":
-        print(f"[bench launcher] the pinned attempt failed with {rc} after {took:.0f} s before any result: "
+    rc, took, printed, failed = _launch_once(n, argv, pin)
+    # Only an ordinary error exit (0 < rc < 128: an exception at the rendezvous / collective set-up) is retried.  A rank killed by
+    # a signal (negative code: SIGSEGV, SIGABRT -- a GPU memory fault, an abort inside a library) is NOT re-run on the box: the run
+    # fails with 128 + signal so that its cause is looked for in the records.
+    if 0 < rc < 128 and pin and not printed and os.environ.get("SMOLTTS_BENCH_NO_FALLBACK") != "1":
+        print(f"[bench launcher] the pinned attempt failed with {rc} (rank {failed}) after {took:.0f} s before any result: "
               "retrying ONCE without per-rank HIP_VISIBLE_DEVICES masks (binding by LOCAL_RANK)", file=sys.stderr, flush=True)
-        rc, _, _ = _launch_once(n, argv, False)
+        note = json.dumps({"rc": rc, "rank": failed, "seconds": round(took, 1)})  # lands on the result line: launcher_fallback / pinned_attempt_failed
+        rc, _, _, _ = _launch_once(n, argv, False, {"SMOLTTS_BENCH_PINNED_ATTEMPT_FAILED": note})
+    if rc < 0:
+        print(f"[bench launcher] rank {failed} was killed by signal {-rc}: no retry", file=sys.stderr, flush=True)
+        rc = 128 - rc
     return rc
+
+
+def launcher_record():
+    """What the self-launcher did before this attempt, for the result line: (launcher_fallback, pinned_attempt_failed)."""
+    note = os.environ.get("SMOLTTS_BENCH_PINNED_ATTEMPT_FAILED")
+    return (True, json.loads(note)) if note else (False, None)
 
 
 def rehearse(args) -> None:
@@ -217,6 +233,8 @@ def rehearse(args) -> None:
         raise SystemExit(3)
     if os.environ.get("SMOLTTS_BENCH_FAIL_IF_PINNED") == "1" and os.environ.get("SMOLTTS_BENCH_PINNED") == "1" and rank == 1:
         raise SystemExit(5)  # test hook: a backend that cannot work under per-rank device masks
+    if os.environ.get("SMOLTTS_BENCH_FAIL_IF_PINNED") == "abort" and os.environ.get("SMOLTTS_BENCH_PINNED") == "1" and rank == 1:
+        os.abort()  # test hook: a rank that dies of a signal at start-up (what a GPU fault looks like to the launcher)
     seen = parallel.ranks_seen("cpu")
     cfg = named_config("tiny")
     arena = offsets = None
@@ -243,7 +261,8 @@ def rehearse(args) -> None:
                           "value": None, "unit": "frames/s", "n_gpus": world, "ranks_seen": seen, "steps": args.steps, "warmup": args.warmup,
                           "utterances_sharded": int(units), "arena_bytes": int(arena.numel()), "arena_identical_on_all_ranks": same_arena,
                           "parity": {"ranks_checked": world, "ranks_passed": int(passed), "arena_checksums_identical": same_arena},
-                          "elapsed_s": round(elapsed, 4), "backend": "gloo"}), flush=True)
+                          "elapsed_s": round(elapsed, 4), "backend": "gloo", "launcher_fallback": launcher_record()[0],
+                          "pinned_attempt_failed": launcher_record()[1]}), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 
@@ -572,7 +591,8 @@ def run_rank(args) -> None:
         okw = dict(embed_mask=numerics.embed_mask, rope_bf16=numerics.rope_bf16, kv_bf16=(args.kv == "bf16"))
         orc = LMOracle(OracleLMConfig.from_dict(ocfg.__dict__), ostate, **okw)
         with torch.no_grad():
-            orc._alloc(B, max_T + nF + 2)
+            nA = min(8, nF)  # frames of the second sample (every host CPU as a thread)
+            orc._alloc(B, max_T + nF + nA + 4)
             hidden = torch.stack([orc.prefill_one(b, torch.from_numpy(mine[b]).long()) for b in range(B)])
             cols_all = []
             t_lm = 0.0
@@ -594,6 +614,32 @@ def run_rank(args) -> None:
             t_mimi = time.perf_counter() - t1
             log(f"  oracle Mimi decode done ({t_mimi:.1f}s)")
             del ref_pcm
+            # SURVEY.md §8d asks for torch.set_num_threads(os.cpu_count()): the same loop continued on every host CPU (the figure above
+            # uses the threads this process may really run on, capped at the 16-CPU share of a one-GPU box)
+            all_cpus = None
+            ncpu = os.cpu_count() or 1
+            if ncpu > torch.get_num_threads():
+                prev = torch.get_num_threads()
+                torch.set_num_threads(ncpu)
+                t_a, cols_a = 0.0, []
+                for f in range(nA + 1):  # the first frame spins the wider pool up, untimed
+                    t1 = time.perf_counter()
+                    ids = orc.slow_head(hidden).argmax(-1)
+                    cds, _ = orc.fast_decode(hidden)
+                    cols = torch.cat([ids[:, None], cds], dim=1)
+                    hidden = orc.decode_cols(cols)
+                    if f > 0:
+                        t_a += time.perf_counter() - t1
+                        cols_a.append(cols)
+                ga = torch.stack(cols_a, dim=1)
+                t1 = time.perf_counter()
+                morc.decode(ga[:, :, 1:].permute(0, 2, 1).contiguous())
+                t_am = time.perf_counter() - t1
+                torch.set_num_threads(prev)
+                all_cpus = {"value": round(B * nA / (t_a + t_am), 2), "unit": "frames/s", "cores": ncpu,
+                            "sample": f"the same loop continued for {nA} frames x {B} utterances with torch.set_num_threads(os.cpu_count()={ncpu}) + their Mimi decode; "
+                                      f"LM {t_a:.2f}s, Mimi {t_am:.2f}s"}
+                log(f"  oracle on all {ncpu} host CPUs: {all_cpus['value']} frames/s")
             # BASELINE configs[0] / SURVEY.md §8d config 1: smoltts_byte_70m, one utterance, the same loop
             cfg70 = named_config("smoltts_byte_70m")
             st70 = synthetic_lm_state(cfg70, seed=0)
@@ -618,6 +664,7 @@ def run_rank(args) -> None:
         cpu = {"value": round(B * nF / (t_lm + t_mimi), 2), "unit": "frames/s", "cores": torch.get_num_threads(), "host_cpus": os.cpu_count(),
                "kind": "port", "sample": f"{nF} decode frames x {B} utterances ({args.model} oracle, fp32 torch eager, KV-cached) "
                f"+ Mimi decode of those frames; LM {t_lm:.2f}s, Mimi {t_mimi:.2f}s; prefill and 1 warm-up frame untimed",
+               "all_cpus": all_cpus,
                "b1_70m": {"value": round(nF / (t70 + t70m), 2), "unit": "frames/s", "sample": f"{nF} decode frames x 1 utterance (smoltts_byte_70m oracle) + Mimi decode; "
                           f"LM {t70:.2f}s, Mimi {t70m:.2f}s (BASELINE configs[0])"}}
         same = np.array_equal(codes[:, : nF + 1], grid.numpy())
@@ -751,6 +798,7 @@ def run_rank(args) -> None:
             "us_per_frame_step": round(us_per_frame_step, 1), "prefill_ms": round(prefill_ms, 2),
             "min_top2_margin": float(margin.min()),
             "first_audio_chunk": first_chunk, "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+            "launcher_fallback": launcher_record()[0], "pinned_attempt_failed": launcher_record()[1],
         }
         out["parity"] = dict(parity or {}, **rank_parity)
         print(json.dumps(out), flush=True)

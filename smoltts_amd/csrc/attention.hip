@@ -272,7 +272,12 @@ __global__ __launch_bounds__(1024) void attn_split_kernel(AttnDev p) {
   const int kk = lane / LPK, dl = lane % LPK;
   const int pos = p.row_pos[row], slot = p.row_slot[row];
   const int HD = p.n_q_heads * 64;
-  if (pos < 0 || pos >= p.cache_len) {  // nothing cached for this row: defined output, no OOB (every part returns: no ticket is taken)
+  // A row whose position lies outside the cache has nothing to attend to.  This guard stands in front of every use of `pos`: the
+  // cache reads below are the only accesses of this kernel whose address depends on an unvalidated input, and for pos >= cache_len
+  // they run past the (slot, head)'s rows -- past the allocation for the last slot, which the ROCm runtime reports by aborting the
+  // process (SIGABRT, exit 134: DESIGN.md 4.5).  Both parts of the pair leave here, so no ticket is taken and the pair's count stays even.
+  // tests/test_attn_split_gpu.py covers pos = -1, cache_len, cache_len + 7.
+  if (pos < 0 || pos >= p.cache_len) {
     if (prt == 0)
       for (int i = tid; i < G * 16; i += blockDim.x) {
         const int k = (h * G + (i >> 4)) * 64 + (i & 15) * 4;
@@ -470,10 +475,10 @@ __global__ __launch_bounds__(1024) void attn_split_kernel(AttnDev p) {
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the one storing wave has drained before its lane 0 signals
-    int old = 0;
-    if (lane == 0) old = __hip_atomic_fetch_add(p.split_ticket + pair, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    old = __builtin_amdgcn_readfirstlane(old);
-    if (((old + 1) % NS) != 0) return;  // not the last arriver of this launch
+    unsigned old = 0;  // (unsigned: the count may wrap, the remainder below stays defined; sessions zero it at every end of frame)
+    if (lane == 0) old = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(p.split_ticket) + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+    if (((old + 1u) % (unsigned)NS) != 0u) return;  // not the last arriver of this launch
     typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
     typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
     float pm[NS], pd[NS];

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/smoltts_hip.h"
@@ -43,18 +44,23 @@ void set_error(const char* fmt, ...);
 // properties of a DEVICE, so a process that moves to a second GPU must set / read them again there.
 struct PerDevice {
   static constexpr int kMax = 64;
-  unsigned long long done_mask = 0;   // bit d: done on device d (launchers run on the caller's thread; races only repeat the call)
+  std::atomic<unsigned long long> done_mask{0};  // bit d: done on device d.  Set only AFTER the guarded call has succeeded (mark_done):
+                                                 // a second host thread (the scheduler's codec thread beside another session) either sees
+                                                 // the bit and the finished call, or repeats the call -- which is idempotent -- itself; a
+                                                 // failed call is retried by the next launch
   int value[kMax] = {0};
   static int current() { int d = 0; (void)hipGetDevice(&d); return d < 0 ? 0 : (d >= kMax ? kMax - 1 : d); }
-  bool first_time(int dev) { const unsigned long long bit = 1ull << dev; const bool first = !(done_mask & bit); done_mask |= bit; return first; }
+  bool done(int dev) const { return (done_mask.load(std::memory_order_acquire) >> dev) & 1ull; }
+  void mark_done(int dev) { done_mask.fetch_or(1ull << dev, std::memory_order_release); }
 };
 inline int device_cu_count() {  // CUs of the current device (cached per device)
   static PerDevice cache;
   const int d = PerDevice::current();
-  if (cache.first_time(d)) {
+  if (!cache.done(d)) {
     int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
     cache.value[d] = n;
+    cache.mark_done(d);
   }
   return cache.value[d];
 }

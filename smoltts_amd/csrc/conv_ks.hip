@@ -177,8 +177,10 @@ template <int NTW>
 int launch_ks(const GemmDev& g, int tiles_per_slot, int nparts, hipStream_t stream) {
   static PerDevice attr;
   const int dev = PerDevice::current();
-  if (attr.first_time(dev))  // > 64 KB of dynamic LDS must be requested per kernel and device
+  if (!attr.done(dev)) {  // > 64 KB of dynamic LDS must be requested per kernel and device
     ST_CHECK_HIP(hipFuncSetAttribute((const void*)conv_ks_kernel<NTW, SMOLTTS_EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KS_LDS_BYTES));
+    attr.mark_done(dev);
+  }
   const long blocks = (long)tiles_per_slot * (g.M / g.rows_per_batch) * nparts;
   hipLaunchKernelGGL((conv_ks_kernel<NTW, SMOLTTS_EPI_STORE>), dim3((unsigned)blocks), dim3(512), KS_LDS_BYTES, stream, g, tiles_per_slot, nparts);
   ST_CHECK_HIP(hipGetLastError());

@@ -243,9 +243,10 @@ int launch_xs(const GemmDev& g, int nsplit, hipStream_t stream) {
   const size_t lds = (size_t)3 * (g.cpt * 4) * RA * 16 + (g.ln_w ? (32 * 64 + 64) * sizeof(float) : 0);
   static PerDevice attr;  // value[d] = the largest size requested on device d so far
   const int dev = PerDevice::current();
-  if (attr.first_time(dev) || (int)lds > attr.value[dev]) {  // > 64 KB of dynamic LDS must be requested per kernel and device
+  if (!attr.done(dev) || (int)lds > attr.value[dev]) {  // > 64 KB of dynamic LDS must be requested per kernel and device
     ST_CHECK_HIP(hipFuncSetAttribute((const void*)conv_xs_kernel<NTW, MT, RA, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr.value[dev] = (int)lds;
+    if ((int)lds > attr.value[dev]) attr.value[dev] = (int)lds;
+    attr.mark_done(dev);
   }
   const int T = g.rows_per_batch > 0 ? g.rows_per_batch : g.M;
   const dim3 grid((T + 16 * MT - 1) / (16 * MT), g.M / T, nsplit);

@@ -86,17 +86,19 @@ __device__ __forceinline__ uint4 load_w16(const char* ptr) {
 }
 
 // fp8 weights (e4m3, per-row scale applied in the epilogue): a lane's 8 bytes -> the bf16x8 A fragment.
-// e4m3 has 3 mantissa bits, so the upper half of the converted fp32 is the exact bf16.
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t bf16_pair(f32x2_t f) {
-  return (__float_as_uint(f[0]) >> 16) | (__float_as_uint(f[1]) & 0xffff0000u);
+// gfx950 converts two e4m3 bytes straight to a bf16 pair (v_cvt_scalef32_pk_bf16_fp8, scale 1.0: e4m3's 3 mantissa bits fit
+// bf16's 7, so the conversion is exact): 4 VALU instructions per fragment on the operand path (round 3 went through fp32:
+// 4 x v_cvt_pk_f32_fp8 + 8 shift / and-or instructions).
+__device__ __forceinline__ uint32_t fp8x2_to_bf16x2(uint32_t v, bool upper) {
+  return upper ? __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v, 1.0f, true))
+               : __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v, 1.0f, false));
 }
 __device__ __forceinline__ bf16x8_t fp8x8_to_bf16x8(uint32_t lo, uint32_t hi) {
   uint4 o;
-  o.x = bf16_pair(__builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false));
-  o.y = bf16_pair(__builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true));
-  o.z = bf16_pair(__builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false));
-  o.w = bf16_pair(__builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true));
+  o.x = fp8x2_to_bf16x2(lo, false);
+  o.y = fp8x2_to_bf16x2(lo, true);
+  o.z = fp8x2_to_bf16x2(hi, false);
+  o.w = fp8x2_to_bf16x2(hi, true);
   return __builtin_bit_cast(bf16x8_t, o);
 }
 template <bool W8, bool NT = false>
@@ -506,9 +508,9 @@ __global__ __launch_bounds__(256) void gemm3_rows_kernel(Gemm3Dev p) {
 //            its <= 2 keys, merged over the 4 key groups (row_ror:8, then lane ^ 16); the weighted V sums travel the same two
 //            steps, each lane handing over the half it does not publish.  Each lane ends up with 2 output values, splits them
 //            into bf16x3 and writes them to LDS in the MFMA B-fragment order of x3.h (R rows instead of 16 per chunk).
-//   phase B  the K loop of gemm3_kernel<1, T, 3, RESID> with the B fragments coming from LDS; same chunk -> wave deal, same
-//            fixed-order reduction, one finishing wave per column tile, same epilogue (residual, fp32 store, X3 emission,
-//            partial sums of squares).
+//   phase B  the other eight waves, which have had the whole weight stream in flight meanwhile (chunk c belongs to GEMM wave c % 8), take the B fragments from LDS, run all the MFMAs and leave their partial tiles in LDS; the
+//            epilogue of gemm3_kernel's RESID case (fixed-order sum of the four partials, residual, fp32 store, X3 emission,
+//            partial sums of squares) runs on waves 0 .. T-1, whose inputs were requested before phase A.
 // Reference: Attention.forward (modeling/model/rq_transformer.py:535-570) at decode time inside forward_generate_fast
 // (mlx_inference/src/smoltts_mlx/lm/rq_transformer.py:194-220, 281-295).
 __device__ __forceinline__ float dpp_ror8(float x) {  // lane i of a 16-lane row <- lane i ^ 8
@@ -520,6 +522,15 @@ __device__ __forceinline__ float row8_sum(float x) {  // sum over the 8 lanes of
   x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));  // row_half_mirror
   return x;
 }
+// Exchange between lane i and lane i ^ 16 on the VALU (v_permlane16_swap_b32, gfx950): after swap16(a, b) an even 16-lane row holds
+// (its own a, the partner's a) and an odd row (the partner's b, its own b) -- so with a == b both lanes of a pair hold (own, partner's)
+// in some order, and a + b / max(a, b) is the pair's sum / maximum in every lane; with a != b the even row's b and the odd row's a
+// have changed places.  No LDS crossbar round trip (ds_bpermute) on the critical path of a lone wave.
+__device__ __forceinline__ void swap16(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
 __device__ __forceinline__ float dot8(float4 a, float4 b, float4 k0, float4 k1) {
   float d0 = a.x * k0.x, d1 = a.y * k0.y;  // two chains: the compiler packs them (v_pk_fma_f32)
   d0 = fmaf(a.z, k0.z, d0); d1 = fmaf(a.w, k0.w, d1);
@@ -530,174 +541,161 @@ __device__ __forceinline__ float dot8(float4 a, float4 b, float4 k0, float4 k1) 
 
 constexpr int AWO_R = 2;  // rows per workgroup
 
+// One (row, pair of kv heads) unit of phase A: what a lane holds between its loads and its arithmetic.
+template <int G, bool TWO>
+struct AwoUnit {
+  float4 ka0, kb0, va0, vb0, ka1, kb1, va1, vb1, qa[G], qb[G];
+  int rl, kvc;
+  bool hv, ok0, ok1;
+};
+
+template <int G, bool TWO>
+__device__ __forceinline__ void awo_load(AwoUnit<G, TWO>& u, const Gemm3Dev& p, int unit, int kv_pairs, int row0, int lane) {
+  const int kq = lane >> 5, jj = (lane >> 3) & 3, hb = jj & 1, m8 = lane & 7;
+  const int L = p.a_pos + 1;  // keys 0 .. a_pos
+  u.rl = unit / kv_pairs;
+  const int kvh = (unit - u.rl * kv_pairs) * 2 + kq, row = row0 + u.rl;  // row == slot
+  u.hv = kvh < p.n_kv_heads;
+  u.kvc = u.hv ? kvh : p.n_kv_heads - 1;
+  const long cb = (((long)row * p.n_kv_heads + u.kvc) * p.cache_len) * 64 + 4 * m8;
+  u.ok0 = jj < L;
+  u.ok1 = TWO && jj + 4 < L;
+  const long o0 = cb + (long)(u.ok0 ? jj : 0) * 64, o1 = cb + (long)(u.ok1 ? jj + 4 : 0) * 64;
+  // K: dims [4m, +4) and [32 + 4m, +4); V: the half this lane publishes (hb) first, the other half second
+  u.ka0 = *reinterpret_cast<const float4*>(p.kc + o0); u.kb0 = *reinterpret_cast<const float4*>(p.kc + o0 + 32);
+  u.va0 = *reinterpret_cast<const float4*>(p.vc + o0 + 32 * hb); u.vb0 = *reinterpret_cast<const float4*>(p.vc + o0 + 32 * (1 - hb));
+  if (TWO) {
+    u.ka1 = *reinterpret_cast<const float4*>(p.kc + o1); u.kb1 = *reinterpret_cast<const float4*>(p.kc + o1 + 32);
+    u.va1 = *reinterpret_cast<const float4*>(p.vc + o1 + 32 * hb); u.vb1 = *reinterpret_cast<const float4*>(p.vc + o1 + 32 * (1 - hb));
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const float* qp = p.aq + (long)row * (p.n_q_heads * 64) + (u.kvc * G + g) * 64 + 4 * m8;
+    u.qa[g] = *reinterpret_cast<const float4*>(qp);
+    u.qb[g] = *reinterpret_cast<const float4*>(qp + 32);
+  }
+}
+
+template <int G, bool TWO>
+__device__ __forceinline__ void awo_compute(const AwoUnit<G, TWO>& u, char* frag, int lane) {
+  constexpr int R = AWO_R;
+  const int hb = (lane >> 3) & 1, m8 = lane & 7;
+  const bool up = (lane & 16) != 0;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const float4 a = make_float4(u.qa[g].x * 0.125f, u.qa[g].y * 0.125f, u.qa[g].z * 0.125f, u.qa[g].w * 0.125f);
+    const float4 b = make_float4(u.qb[g].x * 0.125f, u.qb[g].y * 0.125f, u.qb[g].z * 0.125f, u.qb[g].w * 0.125f);
+    float s0 = row8_sum(dot8(a, b, u.ka0, u.kb0)), s1 = -INFINITY;
+    s0 = u.ok0 ? s0 : -INFINITY;
+    if (TWO) {
+      s1 = row8_sum(dot8(a, b, u.ka1, u.kb1));
+      s1 = u.ok1 ? s1 : -INFINITY;
+    }
+    float mx = TWO ? fmaxf(s0, s1) : s0;
+    mx = fmaxf(mx, dpp_ror8(mx));
+    {
+      float t = mx;
+      swap16(mx, t);
+      mx = fmaxf(mx, t);  // key 0 is always there: finite
+    }
+    const float e0 = __expf(s0 - mx);    // exp(-inf) = 0: keys behind the row's position drop out by themselves
+    float den = e0;
+    float4 oa = make_float4(e0 * u.va0.x, e0 * u.va0.y, e0 * u.va0.z, e0 * u.va0.w);
+    float4 ob = make_float4(e0 * u.vb0.x, e0 * u.vb0.y, e0 * u.vb0.z, e0 * u.vb0.w);
+    if (TWO) {
+      const float e1 = __expf(s1 - mx);
+      den += e1;
+      oa.x = fmaf(e1, u.va1.x, oa.x); oa.y = fmaf(e1, u.va1.y, oa.y); oa.z = fmaf(e1, u.va1.z, oa.z); oa.w = fmaf(e1, u.va1.w, oa.w);
+      ob.x = fmaf(e1, u.vb1.x, ob.x); ob.y = fmaf(e1, u.vb1.y, ob.y); ob.z = fmaf(e1, u.vb1.z, ob.z); ob.w = fmaf(e1, u.vb1.w, ob.w);
+    }
+    den += dpp_ror8(den);
+    {
+      float t = den;
+      swap16(den, t);
+      den += t;
+    }
+    // step 1 (lane ^ 8: the other half's publisher): hand over the sums of the half this lane does not publish
+    oa.x += dpp_ror8(ob.x); oa.y += dpp_ror8(ob.y); oa.z += dpp_ror8(ob.z); oa.w += dpp_ror8(ob.w);
+    // step 2 (lane ^ 16: same four values over the other two key groups): the lower lane publishes (x, y), the upper (z, w); one swap
+    // moves the lower lane's z to the upper and the upper lane's x to the lower, after which x + z is what the lane publishes
+    swap16(oa.x, oa.z);
+    swap16(oa.y, oa.w);
+    float inv = __builtin_amdgcn_rcpf(den);
+    inv = fmaf(fmaf(-den, inv, 1.0f), inv, inv);  // one Newton step: within an ulp of 1 / den
+    const float ox = (oa.x + oa.z) * inv, oy = (oa.y + oa.w) * inv;
+    uint32_t h, mm, l;
+    split3_pair(ox, oy, h, mm, l);
+    const int c = 2 * (u.kvc * G + g) + hb;  // chunk: head, half of its 64 dims
+    char* fp = frag + ((size_t)((c * 3) * 4 + (m8 >> 1)) * R + u.rl) * 16 + (m8 & 1) * 8 + (up ? 4 : 0);
+    if (u.hv) {
+      *reinterpret_cast<uint32_t*>(fp) = h;
+      *reinterpret_cast<uint32_t*>(fp + 4 * R * 16) = mm;
+      *reinterpret_cast<uint32_t*>(fp + 8 * R * 16) = l;
+    }
+  }
+}
+
+constexpr int AWO_NA = 4, AWO_NB = 8, AWO_U = 3;  // attention waves, GEMM waves, 32-k chunks per GEMM wave (K <= 768)
+
 template <int G, int T, bool TWO, bool W8>  // TWO: more than 4 keys (a second key per lane)
-__global__ __launch_bounds__(512) void attn_wo_kernel(Gemm3Dev p) {
+__global__ __launch_bounds__(768) void attn_wo_kernel(Gemm3Dev p) {
   constexpr int WTILE = W8 ? 512 : 1024, WLANE = W8 ? 8 : 16;
-  constexpr int U = 3, R = AWO_R;
+  constexpr int R = AWO_R, NA = AWO_NA, NB = AWO_NB, U = AWO_U;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int nwaves = blockDim.x >> 6;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, q = lane >> 4;
   const int ng = blockIdx.x, row0 = blockIdx.y * R;
   const int nchunks = p.K >> 5;
+  char* frag = reinterpret_cast<char*>(smem);  // [chunk][piece][q][row] x 16 B
+  float4* red4 = reinterpret_cast<float4*>(frag + (size_t)nchunks * 3 * 4 * R * 16);  // [GEMM wave][tile][lane]
   STAMP3(0);
 
-  // ---- phase A loads first (they are the critical path), then the weight stream, then the epilogue inputs
-  char* frag = reinterpret_cast<char*>(smem);  // [chunk][piece][q][row] x 16 B
-  const int L = p.a_pos + 1;                   // keys 0 .. a_pos
-  const int kq = lane >> 5, jj = (lane >> 3) & 3, hb = jj & 1, m8 = lane & 7;
-  const int HD = p.n_q_heads * 64;
-  const int kv_pairs = (p.n_kv_heads + 1) >> 1;
-  int n_units = (p.M - row0 < R ? p.M - row0 : R) * kv_pairs;  // (row, kv pair) units of this workgroup: units wave, wave + nwaves, ..
-  for (int unit = wave; unit < n_units; unit += nwaves) {
-    const int rl = unit / kv_pairs, kvh = (unit - rl * kv_pairs) * 2 + kq;
-    const int row = row0 + rl;  // == slot
-    const bool hv = kvh < p.n_kv_heads;
-    const int kvc = hv ? kvh : p.n_kv_heads - 1;
-    const long cb = (((long)row * p.n_kv_heads + kvc) * p.cache_len) * 64 + 4 * m8;
-    const bool ok0 = jj < L, ok1 = TWO && jj + 4 < L;
-    const long o0 = cb + (long)(ok0 ? jj : 0) * 64, o1 = cb + (long)(ok1 ? jj + 4 : 0) * 64;
-    // K: dims [4m, +4) and [32 + 4m, +4); V: the half this lane publishes (hb) first, the other half second
-    const float4 ka0 = *reinterpret_cast<const float4*>(p.kc + o0), kb0 = *reinterpret_cast<const float4*>(p.kc + o0 + 32);
-    const float4 va0 = *reinterpret_cast<const float4*>(p.vc + o0 + 32 * hb), vb0 = *reinterpret_cast<const float4*>(p.vc + o0 + 32 * (1 - hb));
-    float4 ka1, kb1, va1, vb1;
-    if (TWO) {
-      ka1 = *reinterpret_cast<const float4*>(p.kc + o1); kb1 = *reinterpret_cast<const float4*>(p.kc + o1 + 32);
-      va1 = *reinterpret_cast<const float4*>(p.vc + o1 + 32 * hb); vb1 = *reinterpret_cast<const float4*>(p.vc + o1 + 32 * (1 - hb));
+  // Two kinds of waves, because a CU takes its operands in at ~64 B per clock whatever the waves do: the
+  // attention waves must not queue their few q / K / V loads behind the weight stream, and the weight stream must not wait for
+  // the attention arithmetic.  Waves 0 .. NA-1: phase A, then (waves 0 .. T-1) the epilogue.  Waves NA .. NA+NB-1: the whole
+  // weight tile stream (chunk c belongs to GEMM wave c % NB) and, behind the barrier, all the MFMAs.
+  if (wave < NA) {
+    const int kv_pairs = (p.n_kv_heads + 1) >> 1;
+    const int n_units = (p.M - row0 < R ? p.M - row0 : R) * kv_pairs;  // (row, kv pair) units of this workgroup: wave, wave + NA, ..
+    AwoUnit<G, TWO> un;
+    if (wave < n_units) awo_load(un, p, wave, kv_pairs, row0, lane);
+    // epilogue inputs of the finishing waves (wave f: column tile f): in flight across phase A, the barriers and the K loop
+    const bool fin = wave < T;
+    const int tf = fin ? wave : 0;
+    const int m = row0 + r;
+    const bool row_on = r < R;
+    const bool mvalid = fin && row_on && m < p.M;
+    float4 rr, bb, ga, gb, ws;
+    rr = bb = make_float4(0.f, 0.f, 0.f, 0.f);
+    ga = gb = ws = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (fin) {
+      const int mc = m < p.M ? m : p.M - 1;
+      const int n0r = (ng * T + tf) * 16 + q * 4;
+      const int n0 = n0r < p.N ? n0r : p.N - 4;  // N % 4 == 0
+      if (W8) ws = *reinterpret_cast<const float4*>(p.wscale + n0);
+      rr = *reinterpret_cast<const float4*>(p.resid + (long)mc * p.ldo + n0);
+      if (p.bias != nullptr) bb = *reinterpret_cast<const float4*>(p.bias + n0);
+      if (p.emit.x3a && p.emit.gamma_a) ga = *reinterpret_cast<const float4*>(p.emit.gamma_a + n0);
+      if (p.emit.x3b && p.emit.gamma_b) gb = *reinterpret_cast<const float4*>(p.emit.gamma_b + n0);
     }
-    float4 qa[G], qb[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const float* qp = p.aq + (long)row * HD + (kvc * G + g) * 64 + 4 * m8;
-      qa[g] = *reinterpret_cast<const float4*>(qp);
-      qb[g] = *reinterpret_cast<const float4*>(qp + 32);
+    STAMP3(5);
+    __syncthreads();  // (lets the GEMM waves start their weight stream: see there)
+    if (wave < n_units) awo_compute(un, frag, lane);
+    for (int unit = wave + NA; unit < n_units; unit += NA) {  // (more than 2 x NA / R kv heads: no shipped config)
+      awo_load(un, p, unit, kv_pairs, row0, lane);
+      awo_compute(un, frag, lane);
     }
+    STAMP3(6);
+    __syncthreads();  // the fragments are in LDS
+    __syncthreads();  // the GEMM waves' partial tiles are in LDS
+    STAMP3(3);
+    if (!fin) return;
+    float4 part[NB];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const float4 a = make_float4(qa[g].x * 0.125f, qa[g].y * 0.125f, qa[g].z * 0.125f, qa[g].w * 0.125f);
-      const float4 b = make_float4(qb[g].x * 0.125f, qb[g].y * 0.125f, qb[g].z * 0.125f, qb[g].w * 0.125f);
-      float s0 = row8_sum(dot8(a, b, ka0, kb0)), s1 = -INFINITY;
-      s0 = ok0 ? s0 : -INFINITY;
-      if (TWO) {
-        s1 = row8_sum(dot8(a, b, ka1, kb1));
-        s1 = ok1 ? s1 : -INFINITY;
-      }
-      float mx = TWO ? fmaxf(s0, s1) : s0;
-      mx = fmaxf(mx, dpp_ror8(mx));
-      mx = fmaxf(mx, __shfl_xor(mx, 16));  // key 0 is always there: finite
-      const float e0 = __expf(s0 - mx);    // exp(-inf) = 0: keys behind the row's position drop out by themselves
-      float den = e0;
-      float4 oa = make_float4(e0 * va0.x, e0 * va0.y, e0 * va0.z, e0 * va0.w);
-      float4 ob = make_float4(e0 * vb0.x, e0 * vb0.y, e0 * vb0.z, e0 * vb0.w);
-      if (TWO) {
-        const float e1 = __expf(s1 - mx);
-        den += e1;
-        oa.x = fmaf(e1, va1.x, oa.x); oa.y = fmaf(e1, va1.y, oa.y); oa.z = fmaf(e1, va1.z, oa.z); oa.w = fmaf(e1, va1.w, oa.w);
-        ob.x = fmaf(e1, vb1.x, ob.x); ob.y = fmaf(e1, vb1.y, ob.y); ob.z = fmaf(e1, vb1.z, ob.z); ob.w = fmaf(e1, vb1.w, ob.w);
-      }
-      den += dpp_ror8(den);
-      den += __shfl_xor(den, 16);
-      // step 1 (lane ^ 8: the other half's publisher): hand over the sums of the half this lane does not publish
-      oa.x += dpp_ror8(ob.x); oa.y += dpp_ror8(ob.y); oa.z += dpp_ror8(ob.z); oa.w += dpp_ror8(ob.w);
-      // step 2 (lane ^ 16: same four values over the other two key groups): the lower lane publishes (x, y), the upper (z, w)
-      const bool up = (lane & 16) != 0;
-      const float t0 = __shfl_xor(up ? oa.x : oa.z, 16), t1 = __shfl_xor(up ? oa.y : oa.w, 16);
-      float inv = __builtin_amdgcn_rcpf(den);
-      inv = fmaf(fmaf(-den, inv, 1.0f), inv, inv);  // one Newton step: within an ulp of 1 / den
-      const float ox = ((up ? oa.z : oa.x) + t0) * inv, oy = ((up ? oa.w : oa.y) + t1) * inv;
-      uint32_t h, mm, l;
-      split3_pair(ox, oy, h, mm, l);
-      const int c = 2 * (kvc * G + g) + hb;  // chunk: head, half of its 64 dims
-      char* fp = frag + ((size_t)((c * 3) * 4 + (m8 >> 1)) * R + rl) * 16 + (m8 & 1) * 8 + (up ? 4 : 0);
-      if (hv) {
-        *reinterpret_cast<uint32_t*>(fp) = h;
-        *reinterpret_cast<uint32_t*>(fp + 4 * R * 16) = mm;
-        *reinterpret_cast<uint32_t*>(fp + 8 * R * 16) = l;
-      }
-    }
-  }
-
-  const char* wb[T];
-  bool wv[T];
-  uint4 wf[U][T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    const int ntile = ng * T + t;
-    wv[t] = ntile * 16 < p.N;
-    wb[t] = p.w + (size_t)ntile * nchunks * WTILE + lane * WLANE;
-  }
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int c = wave + u * nwaves;
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-      wf[u][t] = (c < nchunks && wv[t]) ? load_wfrag<W8, false>(wb[t] + (size_t)c * WTILE) : make_uint4(0, 0, 0, 0);
-  }
-
-  // epilogue inputs of the finishing waves (wave f: column tile f): in flight across the barrier and the K loop
-  const bool fin = wave < T;
-  const int tf = fin ? wave : 0;
-  const int m = row0 + r;
-  const bool row_on = r < R;
-  const bool mvalid = fin && row_on && m < p.M;
-  float4 rr, bb, ga, gb, ws;
-  rr = bb = make_float4(0.f, 0.f, 0.f, 0.f);
-  ga = gb = ws = make_float4(1.f, 1.f, 1.f, 1.f);
-  if (fin) {
-    const int mc = m < p.M ? m : p.M - 1;
-    const int n0r = (ng * T + tf) * 16 + q * 4;
-    const int n0 = n0r < p.N ? n0r : p.N - 4;  // N % 4 == 0
-    if (W8) ws = *reinterpret_cast<const float4*>(p.wscale + n0);
-    rr = *reinterpret_cast<const float4*>(p.resid + (long)mc * p.ldo + n0);
-    if (p.bias != nullptr) bb = *reinterpret_cast<const float4*>(p.bias + n0);
-    if (p.emit.x3a && p.emit.gamma_a) ga = *reinterpret_cast<const float4*>(p.emit.gamma_a + n0);
-    if (p.emit.x3b && p.emit.gamma_b) gb = *reinterpret_cast<const float4*>(p.emit.gamma_b + n0);
-  }
-  STAMP3(5);
-  __syncthreads();
-
-  // ---- phase B: K loop, B fragments from LDS (lanes r >= R: zero columns)
-  f32x4 acc[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int c = wave + u * nwaves;
-    if (c < nchunks) {  // wave-uniform
-      const char* fp = frag + ((size_t)((c * 3) * 4 + q) * R + (r & (R - 1))) * 16;
-      uint4 xb[3];
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc) xb[pc] = row_on ? *reinterpret_cast<const uint4*>(fp + pc * 4 * R * 16) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const bf16x8_t a = wfrag_bf16<W8>(wf[u][t]);
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8_t, xb[pc]), acc[t], 0, 0, 0);
-      }
-    }
-  }
-  STAMP3(1);
-  float4* red4 = reinterpret_cast<float4*>(frag + (size_t)nchunks * 3 * 4 * R * 16);  // [wave][tile][lane]
-#pragma unroll
-  for (int t = 0; t < T; ++t) red4[(wave * T + t) * 64 + lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
-  STAMP3(2);
-  __syncthreads();
-  STAMP3(3);
-  if (!fin) return;
-  {
-    float4 part[8];
-#pragma unroll
-    for (int w = 0; w < 8; ++w) part[w] = red4[((w < nwaves ? w : 0) * T + tf) * 64 + lane];
+    for (int w = 0; w < NB; ++w) part[w] = red4[(w * T + tf) * 64 + lane];
     float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < 8; ++w) {
-      const bool on = w < nwaves;
-      v[0] += on ? part[w].x : 0.f;
-      v[1] += on ? part[w].y : 0.f;
-      v[2] += on ? part[w].z : 0.f;
-      v[3] += on ? part[w].w : 0.f;
-    }
+    for (int w = 0; w < NB; ++w) { v[0] += part[w].x; v[1] += part[w].y; v[2] += part[w].z; v[3] += part[w].w; }
     const int ntile = ng * T + tf;
     const int n0 = ntile * 16 + q * 4;
     const bool valid = mvalid && n0 < p.N;
@@ -714,29 +712,73 @@ __global__ __launch_bounds__(512) void attn_wo_kernel(Gemm3Dev p) {
       sq += __shfl_xor(sq, 32);
       if (q == 0 && mvalid && ntile * 16 < p.N) p.emit.ssq[(size_t)m * (p.N >> 4) + ntile] = sq;
     }
+    STAMP3(4);
+    return;
   }
-  STAMP3(4);
+
+  // ---- GEMM waves.  They hold their loads back until the attention waves have issued theirs: the CU's vector memory pipeline
+  // serves requests in arrival order, and phase A -- the critical path -- needs its 26 KB before the K loop needs its 72 KB.
+  const int gw = wave - NA;
+  __syncthreads();
+  uint4 wf[U][T];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int c = gw + u * NB;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int ntile = ng * T + t;
+      wf[u][t] = (c < nchunks && ntile * 16 < p.N) ? load_wfrag<W8, false>(p.w + ((size_t)ntile * nchunks + c) * WTILE + lane * WLANE)
+                                                   : make_uint4(0, 0, 0, 0);
+    }
+  }
+  STAMP3(5);
+  __syncthreads();  // the fragments are in LDS
+  const bool row_on = r < R;
+  f32x4 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int c = gw + u * NB;
+    if (c < nchunks) {  // wave-uniform
+      const char* fp = frag + ((size_t)((c * 3) * 4 + q) * R + (r & (R - 1))) * 16;
+      uint4 xb[3];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) xb[pc] = row_on ? *reinterpret_cast<const uint4*>(fp + pc * 4 * R * 16) : make_uint4(0, 0, 0, 0);
+      bf16x8_t a[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) a[t] = wfrag_bf16<W8>(wf[u][t]);
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)  // tiles innermost: consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], __builtin_bit_cast(bf16x8_t, xb[pc]), acc[t], 0, 0, 0);
+    }
+  }
+  STAMP3(1);
+#pragma unroll
+  for (int t = 0; t < T; ++t) red4[(gw * T + t) * 64 + lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+  STAMP3(2);
+  __syncthreads();  // the partial tiles are in LDS
 }
 
 template <int G, bool W8>
 static int launch_attn_wo_g(const Gemm3Dev& d, hipStream_t stream) {
   const int nchunks = d.K / 32, ntiles = (d.N + 15) / 16;
-  int nwaves = (nchunks + 2) / 3;
-  nwaves = nwaves < 1 ? 1 : (nwaves > 8 ? 8 : nwaves);  // the K split of launch3_fmt (chunks w, w + nwaves, w + 2 nwaves per wave)
   // few rows: one column tile per workgroup so that the weight stream is spread over the chip; many: three (<= one workgroup per
   // CU at 32 rows x 48 tiles)
   const int T = d.M > 16 ? 3 : 1;
-  if (nwaves < T) nwaves = T;
   const dim3 grid((ntiles + T - 1) / T, (d.M + AWO_R - 1) / AWO_R);
   ST_REQUIRE(grid.y <= 65535, SMOLTTS_E_INVALID, "gemm3: M=%d too large for one launch", d.M);
-  const size_t lds = (size_t)nchunks * 3 * 4 * AWO_R * 16 + (size_t)nwaves * T * 1024;
+  const size_t lds = (size_t)nchunks * 3 * 4 * AWO_R * 16 + (size_t)AWO_NB * T * 1024;
   const bool two = d.a_pos + 1 > 4;
+  const dim3 block((AWO_NA + AWO_NB) * 64);
   if (T == 3) {
-    if (two) hipLaunchKernelGGL((attn_wo_kernel<G, 3, true, W8>), grid, dim3(nwaves * 64), lds, stream, d);
-    else hipLaunchKernelGGL((attn_wo_kernel<G, 3, false, W8>), grid, dim3(nwaves * 64), lds, stream, d);
+    if (two) hipLaunchKernelGGL((attn_wo_kernel<G, 3, true, W8>), grid, block, lds, stream, d);
+    else hipLaunchKernelGGL((attn_wo_kernel<G, 3, false, W8>), grid, block, lds, stream, d);
   } else {
-    if (two) hipLaunchKernelGGL((attn_wo_kernel<G, 1, true, W8>), grid, dim3(nwaves * 64), lds, stream, d);
-    else hipLaunchKernelGGL((attn_wo_kernel<G, 1, false, W8>), grid, dim3(nwaves * 64), lds, stream, d);
+    if (two) hipLaunchKernelGGL((attn_wo_kernel<G, 1, true, W8>), grid, block, lds, stream, d);
+    else hipLaunchKernelGGL((attn_wo_kernel<G, 1, false, W8>), grid, block, lds, stream, d);
   }
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;

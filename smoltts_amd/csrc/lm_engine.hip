@@ -60,7 +60,7 @@ struct SmolttsSession {
   int *stage_slots, *stage_last;                     // [B]
   float* margin;             // [B]
   float* attn_part;          // key-split slow attention: partial records (ATT_SPLIT_PART_FLOATS)
-  int* attn_ticket;          // ... and arrival tickets [ATT_SPLIT_MAX_PAIRS], counting up from 0 (zeroed once, at creation)
+  int* attn_ticket;          // ... and arrival tickets [ATT_SPLIT_MAX_PAIRS]: zeroed at creation and again by every commit kernel (end of frame)
   int* margin_at;            // [B] frame * 64 + step of the slot's smallest top-2 gap
   int* codes;                // [B][max_frames][1+n_fast]
   // host staging (pinned)
@@ -229,6 +229,8 @@ struct CommitArgs {
   const float* slow_logits; int slow_cols; SampleArgs slow_sa;
   const float* last_logits; int last_cols; SampleArgs last_sa;
   float* margin;
+  int* attn_ticket;  // the key-split attention's arrival tickets: back to zero at the end of every frame, so that no history (an
+                     // interrupted launch, a caller's odd count) can invert a later launch's "who arrived last" decision
 };
 
 __global__ __launch_bounds__(256) void commit_embed_kernel(CommitArgs a, EmbedTables t, float* xt, EmitDev emit) {
@@ -236,6 +238,8 @@ __global__ __launch_bounds__(256) void commit_embed_kernel(CommitArgs a, EmbedTa
   __shared__ float sh4[4];
   __shared__ ArgmaxScratch s_pick[2];
   const int b = blockIdx.x, tid = threadIdx.x, H = a.H;  // H <= 64: the whole commit happens inside wave 0, in program order
+  if (b == 0 && a.attn_ticket)
+    for (int i = tid; i < ATT_SPLIT_MAX_PAIRS; i += blockDim.x) a.attn_ticket[i] = 0;
   int id_slow = 0, id_last = 0;
   if (a.slow_logits) id_slow = argmax_row(a.slow_logits + (long)b * a.slow_cols, a.slow_cols, (a.slow_cols & 3) == 0, b, a.margin, a.mask, a.slow_sa, s_pick[0]);
   if (a.last_logits) id_last = argmax_row(a.last_logits + (long)b * a.last_cols, a.last_cols, (a.last_cols & 3) == 0, b, a.margin, a.mask, a.last_sa, s_pick[1]);
@@ -391,6 +395,7 @@ int launch_commit_embed(SmolttsSession* s, int do_commit, int advance_pos, hipSt
   a.stop_on_eos = s->stop_on_eos; a.advance_pos = advance_pos; a.do_commit = do_commit;
   a.new_col = s->new_col; a.mask = s->mask; a.cur_col = s->cur_col; a.codes = s->codes; a.pos = s->pos; a.frames = s->frames; a.done = s->done;
   a.margin = s->margin;
+  a.attn_ticket = s->attn_ticket;
   if (picks) {
     a.slow_logits = s->logits_slow; a.slow_cols = c.vocab_size;
     a.slow_sa = SampleArgs{s->temp, s->min_p, s->seed, 0, 0, s->frames, s->salt, s->margin_at};

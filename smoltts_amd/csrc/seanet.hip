@@ -247,8 +247,11 @@ template <int C, int RC, int NW>
 int launch_res(const ResDev& d, int batch, hipStream_t st) {
   using K = ResCfg<C, RC, NW>;
   static PerDevice attr;
-  if (attr.first_time(PerDevice::current()))  // > 64 KB of dynamic LDS must be requested once per kernel and device
+  const int dev = PerDevice::current();
+  if (!attr.done(dev)) {  // > 64 KB of dynamic LDS must be requested once per kernel and device
     ST_CHECK_HIP(hipFuncSetAttribute((const void*)resblock_kernel<C, RC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS));
+    attr.mark_done(dev);
+  }
   const dim3 grid((d.T + K::RT - 1) / K::RT, batch);
   ST_REQUIRE(grid.y <= 65535, SMOLTTS_E_INVALID, "resblock: batch too large");
   hipLaunchKernelGGL((resblock_kernel<C, RC, NW>), grid, dim3(NW * 64), K::LDS, st, d);

@@ -384,8 +384,11 @@ int launch_seanet_last(const MimiLastStageArgs& a, hipStream_t st) {
              SMOLTTS_E_INVALID, "seanet last stage: null or empty argument");
   ST_REQUIRE(a.batch <= 65535, SMOLTTS_E_INVALID, "seanet last stage: batch too large");
   static PerDevice attr;
-  if (attr.first_time(PerDevice::current()))  // > 64 KB of dynamic LDS must be requested once per kernel and device
+  const int dev = PerDevice::current();
+  if (!attr.done(dev)) {  // > 64 KB of dynamic LDS must be requested once per kernel and device
     ST_CHECK_HIP(hipFuncSetAttribute((const void*)seanet_last_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    attr.mark_done(dev);
+  }
   const int tiles_per_slot = (a.T + S - 2) / (S - 1);
   ST_REQUIRE((long)tiles_per_slot * a.batch < (1L << 30), SMOLTTS_E_INVALID, "seanet last stage: too many rows for one launch");
   LastDev d{a.in, (long)a.in_bstride, a.T, (const char*)a.wt, a.bt, (const char*)a.w2, a.b2, (const char*)a.w3, a.b3,

@@ -52,9 +52,26 @@ def test_a_start_up_failure_under_device_masks_is_retried_once_without_them():
     assert "retrying ONCE without per-rank HIP_VISIBLE_DEVICES masks" in r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["ranks_seen"] == 2
+    d = json.loads(lines[0])  # the record says that the line comes from the second attempt, and what became of the first
+    assert d["launcher_fallback"] is True and d["pinned_attempt_failed"]["rc"] == 5 and d["pinned_attempt_failed"]["rank"] in (0, 1)
     # ... and with the fallback switched off the failure stands
     r, _ = _run({"SMOLTTS_BENCH_FAIL_IF_PINNED": "1", "SMOLTTS_BENCH_NO_FALLBACK": "1"}, "--gpus", "2", "--rehearse-launcher")
     assert r.returncode == 5
+
+
+def test_a_rank_killed_by_a_signal_is_not_retried():
+    """A rank that dies of a signal at start-up (a GPU memory fault shows as SIGSEGV / SIGABRT) must not be re-run on the box: no
+    second attempt, exit code 128 + signal, nothing on stdout."""
+    r, _ = _run({"SMOLTTS_BENCH_FAIL_IF_PINNED": "abort"}, "--gpus", "2", "--rehearse-launcher", "--batch", "3")
+    assert r.returncode == 128 + 6, (r.returncode, r.stderr[-2000:])
+    assert "retrying ONCE" not in r.stderr and "killed by signal 6: no retry" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+
+
+def test_an_unretried_run_says_so_on_its_line():
+    r, _ = _run(None, "--gpus", "2", "--rehearse-launcher", "--batch", "3")
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert d["launcher_fallback"] is False and d["pinned_attempt_failed"] is None
 
 
 def test_under_an_external_launcher_the_process_is_a_rank():
