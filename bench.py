@@ -753,23 +753,24 @@ def run_rank(args) -> None:
         t70l = []
         for u in range(200):  # p50 / p95 over 200 prompts
             t70l += first_chunk_ms(eng70, meng, [all_prompts[u % len(all_prompts)]], 1)
-        # BASELINE configs[1]: one 70m stream, every frame decoded to PCM and copied to the host as it appears
-        ls1 = LMSession(eng70, max_batch=1, max_seq=400, max_rows=256, max_frames=160)
-        ms1 = MimiSession(meng, max_batch=1, max_chunk_frames=1)
-        buf1 = torch.zeros(1, 1920, dtype=torch.float32, device=dev)
-        ls1.prefill([all_prompts[0]], stop_on_eos=False)
-        ms1.reset()
-        for f in range(150):
-            if f == 22:  # the first frames warm the graph and the allocator
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-            if f:
-                ls1.decode(1)
-            ms1.decode_chunk(ls1.codes, f, 1, buf1, code_offset=1)
-            _ = buf1.cpu()
-        b1_stream_fps = 128 / (time.perf_counter() - t1)
-        ms1.close(); ls1.close()
-        first_chunk = {"b1_70m_stream_frames_per_s": round(b1_stream_fps, 1), "batch": B, "model": args.model,
+        # BASELINE configs[1]: one 70m stream, every frame decoded to PCM and copied to the host as it appears -- the façade's
+        # streaming loop (generate.stream_pcm: the codec step of frame f beside frame f + 1), and the one-stream loop beside it
+        from smoltts_amd.generate import stream_pcm
+
+        def b1_stream(overlap):
+            ls1 = LMSession(eng70, max_batch=1, max_seq=400, max_rows=256, max_frames=150)
+            ms1 = MimiSession(meng, max_batch=1, max_chunk_frames=1)
+            t1, n = None, 0
+            for f, chunk in enumerate(stream_pcm(ls1, ms1, all_prompts[0], stop_on_eos=False, overlap=overlap)):
+                if f == 21:  # the first frames warm the graph and the allocator
+                    t1 = time.perf_counter()
+                n = f
+            fps = (n - 21) / (time.perf_counter() - t1)
+            ms1.close(); ls1.close()
+            return fps
+
+        b1_stream_fps, b1_serial_fps = b1_stream(True), b1_stream(False)
+        first_chunk = {"b1_70m_stream_frames_per_s": round(b1_stream_fps, 1), "b1_70m_stream_frames_per_s_one_stream": round(b1_serial_fps, 1), "batch": B, "model": args.model,
                        "batch_at_once_ms_p50": round(float(np.median(t150)), 2),
                        "steady_one_arrival_ms_p50": round(float(np.median(t150s)), 2), "steady_one_arrival_ms_p95": round(float(np.percentile(t150s, 95)), 2),
                        "b1_70m_ms_p50": round(float(np.median(t70l)), 2), "b1_70m_ms_p95": round(float(np.percentile(t70l, 95)), 2),

@@ -148,27 +148,28 @@ class SmolTTS:
             turns = [self.prompt_encoder.encode_text_turn("system", system_prompt), *turns]
         return np.concatenate(turns, axis=1).astype(np.int32)
 
-    def stream(self, input: str, voice: Optional[str] = "heart", generation_settings=None) -> Iterator["np.ndarray"]:
+    def stream(self, input: str, voice: Optional[str] = "heart", generation_settings=None, overlap: bool = True) -> Iterator["np.ndarray"]:
         """Yields one 1920-sample float32 chunk per generated frame, including the terminating
         <|im_end|> frame (reference stream, __init__.py:83-95, decodes vq_tensor[:, 1:, :] of every
-        frame).  The codec carries its streaming state, so the chunks concatenate to the batch decode."""
+        frame).  The codec carries its streaming state, so the chunks concatenate to the batch decode.
+        ``overlap``: the codec step of frame f runs beside frame f + 1 on a second stream (``generate.stream_pcm``); the chunks
+        are the same numbers either way."""
         import numpy as np
-        import torch
 
-        from .engine import MimiSession
-        from .generate import SingleBatchGenerator
+        from .engine import LMSession, MimiSession
+        from .generate import _apply_sampling, stream_pcm
 
-        prompt = self._get_prompt(input, voice if voice is not None else "0")
-        gen = SingleBatchGenerator(self.lm, prompt, self._settings(generation_settings))
+        prompt = np.asarray(self._get_prompt(input, voice if voice is not None else "0"))
+        if prompt.ndim == 3:
+            prompt = prompt[0]
+        settings = self._settings(generation_settings)
+        max_new = settings.max_new_tokens if settings.max_new_tokens is not None else self.config.max_seq_len
+        T = int(prompt.shape[1])
+        sess = LMSession(self.lm, 1, max_seq=min(self.config.max_seq_len, T + max_new + 2), max_rows=T, max_frames=max_new + 1)
+        _apply_sampling(sess, settings)
         msess = MimiSession(self.codec, max_batch=1, max_chunk_frames=1)
-        msess.reset()
-        pcm = torch.empty(1, 1920, dtype=torch.float32, device="cuda")
-        nq = self.config.num_codebooks
         try:
-            for frame in gen:
-                codes = torch.from_numpy(frame.vq_tensor[0, -nq:, 0].astype(np.int32)).reshape(1, 1, nq).cuda()
-                msess.decode_chunk(codes, 0, 1, pcm, code_offset=0)
-                yield pcm.cpu().numpy().reshape(-1).copy()
+            yield from stream_pcm(sess, msess, prompt, stop_on_eos=True, overlap=overlap)
         finally:
             msess.close()
-            gen.close()
+            sess.close()

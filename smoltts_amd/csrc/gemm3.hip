@@ -539,6 +539,9 @@ __device__ __forceinline__ float dot8(float4 a, float4 b, float4 k0, float4 k1) 
   return d0 + d1;
 }
 
+#ifndef SMOLTTS_DBG_AWO_ORDER  // 0 (timing experiments): the GEMM waves start their weight stream at once
+#define SMOLTTS_DBG_AWO_ORDER 1
+#endif
 constexpr int AWO_R = 2;  // rows per workgroup
 
 // One (row, pair of kv heads) unit of phase A: what a lane holds between its loads and its arithmetic.
@@ -679,7 +682,9 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(Gemm3Dev p) {
       if (p.emit.x3b && p.emit.gamma_b) gb = *reinterpret_cast<const float4*>(p.emit.gamma_b + n0);
     }
     STAMP3(5);
+#if SMOLTTS_DBG_AWO_ORDER
     __syncthreads();  // (lets the GEMM waves start their weight stream: see there)
+#endif
     if (wave < n_units) awo_compute(un, frag, lane);
     for (int unit = wave + NA; unit < n_units; unit += NA) {  // (more than 2 x NA / R kv heads: no shipped config)
       awo_load(un, p, unit, kv_pairs, row0, lane);
@@ -719,7 +724,9 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(Gemm3Dev p) {
   // ---- GEMM waves.  They hold their loads back until the attention waves have issued theirs: the CU's vector memory pipeline
   // serves requests in arrival order, and phase A -- the critical path -- needs its 26 KB before the K loop needs its 72 KB.
   const int gw = wave - NA;
+#if SMOLTTS_DBG_AWO_ORDER
   __syncthreads();
+#endif
   uint4 wf[U][T];
 #pragma unroll
   for (int u = 0; u < U; ++u) {

@@ -17,7 +17,7 @@ generator is not reproducible across processes, so parity for the sampled modes 
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Any, List, Optional, Sequence
+from typing import Iterator, Any, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -182,3 +182,67 @@ def generate_blocking(model: LMEngine, prompt: np.ndarray, generation_settings: 
     if not out:
         return np.zeros((1, model.cfg.num_codebooks if audio_only else model.grid_height, 0), dtype=np.uint32)
     return np.concatenate(out, axis=-1)
+
+
+def stream_pcm(session: LMSession, msession, prompt: np.ndarray, stop_on_eos: bool = True, max_frames: Optional[int] = None,
+               overlap: bool = True) -> Iterator[np.ndarray]:
+    """One utterance in slot 0 of ``session`` -> one 1920-sample float32 chunk per generated frame, as the reference's
+    ``SmolTTS.stream`` yields them (mlx_inference/src/smoltts_mlx/__init__.py:83-95: every frame of ``SingleBatchGenerator`` through
+    ``codec.decode_step``), the terminating ``<|im_end|>`` frame included.
+
+    At one utterance both halves of a frame are chains of dependent launches that leave the chip almost empty (188 LM launches,
+    ~100 codec launches: DESIGN.md 5), so with ``overlap`` they run side by side: frame f + 1 is queued on the LM stream before
+    the codec step of frame f goes out on a second stream -- the host has waited for frame f's event by then, it never parks a
+    device-side wait in a queue.  Every chunk still leaves as soon as its own codec step has run; the numbers are those of the
+    one-stream loop (``overlap=False``), only the order in which the GPU sees the launches changes.  A frame queued behind the
+    last one is not a frame: a stopped slot is frozen (smoltts_lm_decode)."""
+    s = session
+    limit = s.max_frames if max_frames is None else min(max_frames, s.max_frames)
+    dev = s.engine.device
+    lm_stream = torch.cuda.Stream(dev) if overlap else torch.cuda.current_stream(dev)
+    codec_stream = torch.cuda.Stream(dev) if overlap else lm_stream
+    caller = torch.cuda.current_stream(dev)
+    lm_stream.wait_stream(caller)
+    codec_stream.wait_stream(caller)
+    pcm_dev = torch.empty(1, 1920, dtype=torch.float32, device=dev)
+    pcm_host = torch.empty(1, 1920, dtype=torch.float32).pin_memory()
+    state_host = torch.zeros(2, dtype=torch.int32).pin_memory()  # n_frames[0], done[0]
+    with torch.cuda.stream(codec_stream):
+        msession.reset()
+    with torch.cuda.stream(lm_stream):
+        s.prefill([prompt], stop_on_eos=stop_on_eos)  # frame 0
+        ev = torch.cuda.Event()
+        ev.record(lm_stream)
+    f = 0
+    try:
+        while f < limit:
+            nxt = None
+            if overlap and f + 1 < limit:
+                with torch.cuda.stream(lm_stream):
+                    s.decode(1)  # frame f + 1 runs beside the codec step of frame f
+                    nxt = torch.cuda.Event()
+                    nxt.record(lm_stream)
+            ev.synchronize()  # frame f is in the output ring
+            with torch.cuda.stream(codec_stream):
+                state_host[0:1].copy_(s.n_frames[0:1], non_blocking=True)
+                state_host[1:2].copy_(s.done[0:1], non_blocking=True)
+                msession.decode_chunk(s.codes[:, f:f + 1], 0, 1, pcm_dev, code_offset=1)  # (decode_chunk writes frame f0 at pcm[:, 1920 f0:])
+                pcm_host.copy_(pcm_dev, non_blocking=True)
+            codec_stream.synchronize()
+            n, done = int(state_host[0]), int(state_host[1])
+            if n <= f:  # the slot had stopped before this frame
+                break
+            yield pcm_host.numpy().reshape(-1).copy()
+            if done and n == f + 1:
+                break
+            if not overlap and f + 1 < limit:
+                s.decode(1)
+                nxt = torch.cuda.Event()
+                nxt.record(lm_stream)
+            if nxt is None:
+                break
+            ev = nxt
+            f += 1
+    finally:
+        lm_stream.synchronize()
+        codec_stream.synchronize()

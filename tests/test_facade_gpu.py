@@ -59,6 +59,20 @@ def test_stream_chunks_concatenate_to_batch_decode(setup):
     assert _rms(np.concatenate(chunks) - ref) <= 1e-4
 
 
+def test_overlapped_stream_yields_the_same_chunks(setup):
+    """``stream`` runs the codec step of frame f beside frame f + 1 (generate.stream_pcm): same chunks, bit for bit, as the
+    one-stream loop, also when the utterance ends by <|im_end|> or by its frame budget."""
+    from smoltts_amd.config import GenerationSettings
+
+    cfg, state, mst, tts, orc, morc, _ = setup
+    for n in (1, 2, 9):
+        gs = GenerationSettings.greedy(max_new_tokens=n)
+        a = list(tts.stream("two streams, one answer", "sky", generation_settings=gs, overlap=True))
+        b = list(tts.stream("two streams, one answer", "sky", generation_settings=gs, overlap=False))
+        assert len(a) == len(b) == n + 1
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
 def test_generate_blocking_and_pth_checkpoint(setup):
     from smoltts_amd import SmolTTS
     from smoltts_amd.config import GenerationSettings
