@@ -591,8 +591,7 @@ def run_rank(args) -> None:
         okw = dict(embed_mask=numerics.embed_mask, rope_bf16=numerics.rope_bf16, kv_bf16=(args.kv == "bf16"))
         orc = LMOracle(OracleLMConfig.from_dict(ocfg.__dict__), ostate, **okw)
         with torch.no_grad():
-            nA = min(8, nF)  # frames of the second sample (every host CPU as a thread)
-            orc._alloc(B, max_T + nF + nA + 4)
+            orc._alloc(B, max_T + nF + 2)
             hidden = torch.stack([orc.prefill_one(b, torch.from_numpy(mine[b]).long()) for b in range(B)])
             cols_all = []
             t_lm = 0.0
@@ -614,32 +613,6 @@ def run_rank(args) -> None:
             t_mimi = time.perf_counter() - t1
             log(f"  oracle Mimi decode done ({t_mimi:.1f}s)")
             del ref_pcm
-            # SURVEY.md §8d asks for torch.set_num_threads(os.cpu_count()): the same loop continued on every host CPU (the figure above
-            # uses the threads this process may really run on, capped at the 16-CPU share of a one-GPU box)
-            all_cpus = None
-            ncpu = os.cpu_count() or 1
-            if ncpu > torch.get_num_threads():
-                prev = torch.get_num_threads()
-                torch.set_num_threads(ncpu)
-                t_a, cols_a = 0.0, []
-                for f in range(nA + 1):  # the first frame spins the wider pool up, untimed
-                    t1 = time.perf_counter()
-                    ids = orc.slow_head(hidden).argmax(-1)
-                    cds, _ = orc.fast_decode(hidden)
-                    cols = torch.cat([ids[:, None], cds], dim=1)
-                    hidden = orc.decode_cols(cols)
-                    if f > 0:
-                        t_a += time.perf_counter() - t1
-                        cols_a.append(cols)
-                ga = torch.stack(cols_a, dim=1)
-                t1 = time.perf_counter()
-                morc.decode(ga[:, :, 1:].permute(0, 2, 1).contiguous())
-                t_am = time.perf_counter() - t1
-                torch.set_num_threads(prev)
-                all_cpus = {"value": round(B * nA / (t_a + t_am), 2), "unit": "frames/s", "cores": ncpu,
-                            "sample": f"the same loop continued for {nA} frames x {B} utterances with torch.set_num_threads(os.cpu_count()={ncpu}) + their Mimi decode; "
-                                      f"LM {t_a:.2f}s, Mimi {t_am:.2f}s"}
-                log(f"  oracle on all {ncpu} host CPUs: {all_cpus['value']} frames/s")
             # BASELINE configs[0] / SURVEY.md §8d config 1: smoltts_byte_70m, one utterance, the same loop
             cfg70 = named_config("smoltts_byte_70m")
             st70 = synthetic_lm_state(cfg70, seed=0)
@@ -664,7 +637,9 @@ def run_rank(args) -> None:
         cpu = {"value": round(B * nF / (t_lm + t_mimi), 2), "unit": "frames/s", "cores": torch.get_num_threads(), "host_cpus": os.cpu_count(),
                "kind": "port", "sample": f"{nF} decode frames x {B} utterances ({args.model} oracle, fp32 torch eager, KV-cached) "
                f"+ Mimi decode of those frames; LM {t_lm:.2f}s, Mimi {t_mimi:.2f}s; prefill and 1 warm-up frame untimed",
-               "all_cpus": all_cpus,
+               "cores_note": "threads = the CPUs this process may run on, capped at the 16-CPU share of a one-GPU box (gpurun); a sample with "
+                             "torch.set_num_threads(os.cpu_count() = 256) was tried in round 4 and did not finish one frame in 7 minutes under that share "
+                             "(256 OpenMP threads on 16 CPUs), so there is no all-CPU figure",
                "b1_70m": {"value": round(nF / (t70 + t70m), 2), "unit": "frames/s", "sample": f"{nF} decode frames x 1 utterance (smoltts_byte_70m oracle) + Mimi decode; "
                           f"LM {t70:.2f}s, Mimi {t70m:.2f}s (BASELINE configs[0])"}}
         same = np.array_equal(codes[:, : nF + 1], grid.numpy())
