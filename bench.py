@@ -564,7 +564,10 @@ def run_rank(args) -> None:
         step_ach = sb / (us_per_frame_step * 1e-6) / 1e9
         roofline = {"bound": "hbm", "kernel": "gemm3_kernel<1, 3, 3, 2, false, NT> = MT 1, T 3, U 3, SwiGLU epilogue, bf16 weights (RMSNorm-scaled w1|w3 GEMM; NT = non-temporal weight loads: the 10 slow layers' launches, not the 32 depth launches)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "traffic_source": traffic_src, "avg_us": round(avg_us, 3), "rocprof_avg_us": rocprof_us, "rocprof_source": rocprof_src,
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "traffic_kind": "bytes the L2s requested from the fabric (L2 misses; Infinity-Cache hits are counted), not HBM bytes: of this kernel's 42 launches per "
+                                    "frame the 10 of the slow blocks stream their weights from HBM (non-temporal loads), the 32 of the depth transformer re-read "
+                                    "weights the Infinity Cache holds -- `peak` is the HBM rate and a loose ceiling for those", "avg_us": round(avg_us, 3), "rocprof_avg_us": rocprof_us, "rocprof_source": rocprof_src,
                     "launches_timed": 8 * n_per_frame * 3, "bytes_per_launch": bytes_alg,
                     "method": "in situ: frame graph replayed with this kernel's launches duplicated (smoltts_session_measure_duplicate), HIP events on the launch stream; frac = achieved / peak from avg_us",
                     "step": {"bytes_per_frame_step": int(sb), "parts": {k: int(v) for k, v in parts.items()}, "mean_context": round(L_mean, 1),

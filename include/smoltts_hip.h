@@ -182,6 +182,24 @@ int smoltts_lm_prefill_deferred(SmolttsSession* s, const int32_t* grid_dev, cons
                                 const int32_t* last_row_host, int32_t n_slots, int32_t stop_on_eos,
                                 void* stream);
 
+/* Prompt prefill BESIDE the decode frames of the same session (ABI 5; serving: refilling a slot no longer stops the other slots).
+ * Three calls replace smoltts_lm_prefill_deferred:
+ *   smoltts_lm_park_slots   (frame stream) the listed slots -- idle, their previous tenants gone -- are frozen with their position
+ *                           counter at pos_host[i] = the new prompt's last position T-1: the rows their idle decode steps write
+ *                           land there, where the tenant's first frame writes anyway;
+ *   smoltts_lm_prefill_side (any stream, once the park has RUN: wait for it on the host or by event) KV-cache rows of the prompt
+ *                           rows, computed on a workspace of its own -- it shares nothing with concurrently running frames but the
+ *                           KV rows 0 .. T-2 of the parked slots;
+ *   smoltts_lm_start_slots  (frame stream, once the side call has finished) arms the slots exactly as the deferred prefill does:
+ *                           the next decode frame takes the last prompt column as its input and emits frame 0.
+ * Same arguments as smoltts_lm_prefill_deferred, split over the calls; grid_dev / row_pos_dev must stay valid until the start call
+ * has run.  Ids are those of the in-line prefill (same kernels, same order; tests/test_side_prefill_gpu.py). */
+int smoltts_lm_park_slots(SmolttsSession* s, const int32_t* slots_host, const int32_t* pos_host, int32_t n_slots, void* stream);
+int smoltts_lm_prefill_side(SmolttsSession* s, const int32_t* grid_dev, const int32_t* row_slot_dev, const int32_t* row_pos_dev,
+                            int32_t n_rows, void* stream);
+int smoltts_lm_start_slots(SmolttsSession* s, const int32_t* grid_dev, const int32_t* row_pos_dev, const int32_t* slots_host,
+                           const int32_t* last_row_host, int32_t n_slots, int32_t stop_on_eos, void* stream);
+
 /* Decode n_frames further frames for every slot of the session: each frame feeds the previous
  * column back (slow step at the slot's next position), then slow head + n_fast depth steps, all
  * greedy and on device; the frame loop is a captured hipGraph replayed n_frames times.  Slots that

@@ -47,6 +47,11 @@ struct SmolttsSession {
   float* qt;                 // [B][max(Hq, fast Hq)*64]
   char *x3n, *x3n2, *x3a, *x3h;  // X3 operands: normed stream (2 consumers), attention out, SwiGLU out
   float* ssq;                // [rows][dim/16] partial sums of squares of the stream
+  // side workspace of smoltts_lm_prefill_side (prompt rows of NEW tenants beside the decode frames of the others): a second set
+  // of everything the slow layers write that is not a KV-cache row
+  float *sd_xr, *sd_qr;
+  char *sd_x3n, *sd_x3a, *sd_x3h;
+  float* sd_ssq;
   float* logits;             // [B][max(vocab, codebook)]: the depth heads' rows
   float* logits_slow;        // [B][vocab]: the slow head's rows (picked by the commit kernel at the end of the frame)
   // caches
@@ -128,6 +133,12 @@ void carve(SmolttsSession* s, char* base, size_t* total) {
   s->x3a = cv.take<char>(R16 * dmax * 6);
   s->x3h = cv.take<char>(R16 * imx * 6);
   s->ssq = cv.take<float>(R16 * (dmax / 16));
+  s->sd_xr = cv.take<float>(R * c.dim);
+  s->sd_qr = cv.take<float>(R * c.n_head * 64);
+  s->sd_x3n = cv.take<char>(R16 * (size_t)c.dim * 6);
+  s->sd_x3a = cv.take<char>(R16 * (size_t)c.dim * 6);
+  s->sd_x3h = cv.take<char>(R16 * (size_t)c.inter * 6);
+  s->sd_ssq = cv.take<float>(R16 * (c.dim / 16));
   s->logits = cv.take<float>(B * (size_t)imax(c.vocab_size, c.codebook_size));
   s->logits_slow = cv.take<float>(B * (size_t)c.vocab_size);
   const size_t kv = (size_t)c.n_layer * B * c.n_kv_head * s->max_seq * 64 * (s->kv_format == SMOLTTS_KV_BF16 ? 2 : 4);
@@ -209,6 +220,15 @@ __global__ void slot_park_kernel(int B, int n_slots, const int* slots, const int
   if (b >= B) return;
   for (int i = 0; i < n_slots; ++i)
     if (slots[i] == b) { pos[b] = row_pos[last_row[i]] + 1; done[b] = 1; mask[b] = 0; }
+}
+
+// The same with the parking positions given by the host (smoltts_lm_park_slots): the slots of tenants whose prompts are about to
+// be prefilled beside the running frames.
+__global__ void slot_parkpos_kernel(int B, int n_slots, const int* slots, const int* where, int* pos, int* done, int* mask) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  for (int i = 0; i < n_slots; ++i)
+    if (slots[i] == b) { pos[b] = where[i]; done[b] = 1; mask[b] = 0; }
 }
 
 // End of frame (lm/generate.py:143-171) and start of the next one, one workgroup per slot:
@@ -888,6 +908,58 @@ int smoltts_lm_prefill_deferred(SmolttsSession* s, const int32_t* grid_dev, cons
   // KV rows of the whole prompt (the last column's row is recomputed by the first decode frame, identically)
   ST_TRY(embed_rows(s, grid_dev, n_rows, s->xr, st));
   ST_TRY(run_slow_layers(s, s->xr, s->qr, n_rows, row_pos_dev, row_slot_dev, /*publish_hidden=*/false, st));
+  hipLaunchKernelGGL(slot_start_kernel, dim3((s->B + 63) / 64), dim3(64), 0, st, s->B, 1 + s->e->cfg.n_fast, n_slots, s->stage_slots,
+                     s->stage_last, row_pos_dev, grid_dev, s->pos, s->frames, s->done, s->margin, s->cur_col, s->salt);
+  ST_CHECK_HIP(hipGetLastError());
+  ST_TRY(launch_commit_embed(s, /*do_commit=*/0, 0, st));  // mask = !done; embed every slot's (new) current column
+  s->prefilled = true;
+  return SMOLTTS_OK;
+}
+
+// ---- prompt prefill beside the decode frames (serving: the refill of a slot no longer stops the other slots' ticks)
+//   tick stream:   ... tick k-1 | park(new slots) | tick k ............ | start(new slots) | tick k+1 (their frame 0) ...
+//   side stream:                     (host saw the park done) prefill_side(new prompts)  ^ host saw it done
+// The side call shares nothing with the frames but the KV cache, and of that only rows 0 .. T-2 of the parked slots: their idle
+// decode rows write at the parking position T-1 (rewritten by the tenant's first frame) and read garbage nobody keeps.
+int smoltts_lm_park_slots(SmolttsSession* s, const int32_t* slots_host, const int32_t* pos_host, int32_t n_slots, void* stream) {
+  ST_REQUIRE(s && slots_host && pos_host, SMOLTTS_E_INVALID, "lm_park_slots: null argument");
+  ST_REQUIRE(n_slots > 0 && n_slots <= s->B, SMOLTTS_E_CAPACITY, "lm_park_slots: %d slots, session holds %d", n_slots, s->B);
+  for (int i = 0; i < n_slots; ++i) {
+    ST_REQUIRE(slots_host[i] >= 0 && slots_host[i] < s->B, SMOLTTS_E_INVALID, "lm_park_slots: slot %d out of range", slots_host[i]);
+    ST_REQUIRE(pos_host[i] >= 0 && pos_host[i] < s->max_seq, SMOLTTS_E_INVALID, "lm_park_slots: position %d outside the cache (%d)", pos_host[i], s->max_seq);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  ST_TRY(stage_upload(s, slots_host, pos_host, n_slots, st));
+  hipLaunchKernelGGL(slot_parkpos_kernel, dim3((s->B + 63) / 64), dim3(64), 0, st, s->B, n_slots, s->stage_slots, s->stage_last, s->pos, s->done, s->mask);
+  ST_CHECK_HIP(hipGetLastError());
+  return launch_commit_embed(s, /*do_commit=*/0, 0, st);  // mask = !done for the next frame
+}
+
+int smoltts_lm_prefill_side(SmolttsSession* s, const int32_t* grid_dev, const int32_t* row_slot_dev, const int32_t* row_pos_dev,
+                            int32_t n_rows, void* stream) {
+  ST_REQUIRE(s && grid_dev && row_slot_dev && row_pos_dev, SMOLTTS_E_INVALID, "lm_prefill_side: null argument");
+  ST_REQUIRE(n_rows > 0 && n_rows <= s->max_rows, SMOLTTS_E_CAPACITY, "lm_prefill_side: %d rows, session holds %d", n_rows, s->max_rows);
+  SmolttsSession side = *s;  // the same engine, caches and options; every activation buffer of the slow layers swapped for the side set
+  side.xr = s->sd_xr; side.qr = s->sd_qr; side.x3n = s->sd_x3n; side.x3a = s->sd_x3a; side.x3h = s->sd_x3h; side.ssq = s->sd_ssq;
+  side.split_attn = false;  // (the key-split attention's records and tickets belong to the frames)
+  side.dup_code = -1;
+  hipStream_t st = (hipStream_t)stream;
+  ST_TRY(embed_rows(&side, grid_dev, n_rows, side.xr, st));
+  return run_slow_layers(&side, side.xr, side.qr, n_rows, row_pos_dev, row_slot_dev, /*publish_hidden=*/false, st);
+}
+
+int smoltts_lm_start_slots(SmolttsSession* s, const int32_t* grid_dev, const int32_t* row_pos_dev, const int32_t* slots_host,
+                           const int32_t* last_row_host, int32_t n_slots, int32_t stop_on_eos, void* stream) {
+  ST_REQUIRE(s && grid_dev && row_pos_dev && slots_host && last_row_host, SMOLTTS_E_INVALID, "lm_start_slots: null argument");
+  ST_REQUIRE(n_slots > 0 && n_slots <= s->B, SMOLTTS_E_CAPACITY, "lm_start_slots: %d slots, session holds %d", n_slots, s->B);
+  for (int i = 0; i < n_slots; ++i) {
+    ST_REQUIRE(slots_host[i] >= 0 && slots_host[i] < s->B, SMOLTTS_E_INVALID, "lm_start_slots: slot %d out of range", slots_host[i]);
+    ST_REQUIRE(last_row_host[i] >= 0 && last_row_host[i] < s->max_rows, SMOLTTS_E_INVALID, "lm_start_slots: last_row %d out of range", last_row_host[i]);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (s->stop_on_eos != stop_on_eos) drop_graphs(s);  // the flag is baked into the captured commit nodes
+  s->stop_on_eos = stop_on_eos;
+  ST_TRY(stage_upload(s, slots_host, last_row_host, n_slots, st));
   hipLaunchKernelGGL(slot_start_kernel, dim3((s->B + 63) / 64), dim3(64), 0, st, s->B, 1 + s->e->cfg.n_fast, n_slots, s->stage_slots,
                      s->stage_last, row_pos_dev, grid_dev, s->pos, s->frames, s->done, s->margin, s->cur_col, s->salt);
   ST_CHECK_HIP(hipGetLastError());

@@ -104,7 +104,7 @@ _EXPORTS = [
     "smoltts_mimi_slab_bytes", "smoltts_mimi_session_create", "smoltts_mimi_session_destroy", "smoltts_mimi_reset",
     "smoltts_mimi_decode_chunk", "smoltts_k_gemm", "smoltts_k_attention", "smoltts_k_embed", "smoltts_k_argmax",
     "smoltts_k_layernorm", "smoltts_k_gemm3", "smoltts_k_x3_pack",
-    "smoltts_session_measure_duplicate", "smoltts_session_margin_at", "smoltts_session_drop_graph", "smoltts_session_set_frames_per_graph", "smoltts_engine_fast_qkv_bytes", "smoltts_engine_build_fast_qkv", "smoltts_session_set_option", "smoltts_gemm3_attn_fusable", "smoltts_k_attention_split", "smoltts_k_attention_rows3",
+    "smoltts_session_measure_duplicate", "smoltts_session_margin_at", "smoltts_session_drop_graph", "smoltts_session_set_frames_per_graph", "smoltts_engine_fast_qkv_bytes", "smoltts_engine_build_fast_qkv", "smoltts_session_set_option", "smoltts_gemm3_attn_fusable", "smoltts_lm_park_slots", "smoltts_lm_prefill_side", "smoltts_lm_start_slots", "smoltts_k_attention_split", "smoltts_k_attention_rows3",
     "smoltts_session_slab_bytes_kv", "smoltts_session_create_kv", "smoltts_k_attention_kv", "smoltts_session_set_sampling", "smoltts_k_sample",
     "smoltts_lm_prefill_chunk", "smoltts_lm_prefill_deferred", "smoltts_mimi_reset_slots", "smoltts_mimi_encoder_create", "smoltts_mimi_encoder_destroy", "smoltts_mimi_encode_frames",
     "smoltts_mimi_encode_workspace_bytes", "smoltts_mimi_encode",
@@ -179,6 +179,9 @@ def load_library(path: Optional[Path] = None):
                                                 C.c_int32, C.c_void_p]
     lib.smoltts_lm_prefill_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                              C.c_void_p]
+    lib.smoltts_lm_park_slots.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.smoltts_lm_prefill_side.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.smoltts_lm_start_slots.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.smoltts_mimi_encoder_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.smoltts_mimi_encoder_destroy.argtypes = [C.c_void_p]
     lib.smoltts_mimi_encoder_destroy.restype = None
@@ -408,17 +411,8 @@ class LMSession:
         if os.environ.get("SMOLTTS_STREAM_W") is not None:  # mask of SMOLTTS_STREAM_W_* bits
             check(self.lib.smoltts_session_set_option(self.handle, OPT_STREAM_W, int(os.environ["SMOLTTS_STREAM_W"])), "smoltts_session_set_option")
 
-    def prefill(self, prompts: Sequence[np.ndarray], slots: Optional[Sequence[int]] = None, stop_on_eos: bool = True,
-                pos0: Optional[Sequence[int]] = None, final: bool = True, defer_frame0: bool = False) -> None:
-        """prompts: one ``(1 + n_fast, T_b)`` int grid per utterance; emits frame 0 of each slot.
-
-        Chunked prefill: ``pos0[b]`` is the position of the first column of ``prompts[b]`` (its earlier columns
-        went through previous calls with ``final=False``, which fill the KV cache only and leave the slot idle).
-        ``defer_frame0``: no frame-0 tail here; the next ``decode`` call emits frame 0 as its first frame (serving loop)."""
-        slots = list(range(len(prompts))) if slots is None else list(slots)
-        if len(slots) != len(prompts) or len(set(slots)) != len(slots):
-            raise ValueError("slots must be distinct and match prompts")
-        pos0 = [0] * len(prompts) if pos0 is None else list(pos0)
+    def _rows(self, prompts, slots, pos0):
+        """Prompt grids -> (grid rows, row slots, row positions on the device, last row per utterance, row count)."""
         cfg = self.engine.cfg
         cols, rslot, rpos, last = [], [], [], []
         n = 0
@@ -438,8 +432,56 @@ class LMSession:
             last.append(n - 1)
         if n > self.max_rows:
             raise SmolttsError(f"{n} prompt rows exceed the session's max_rows={self.max_rows}")
-        dev = self.engine.device
-        grid_d, rslot_d, rpos_d = upload([np.concatenate(cols), np.concatenate(rslot), np.concatenate(rpos)], dev)
+        grid_d, rslot_d, rpos_d = upload([np.concatenate(cols), np.concatenate(rslot), np.concatenate(rpos)], self.engine.device)
+        return grid_d, rslot_d, rpos_d, last, n
+
+    # ---- prompt prefill beside the decode frames (include/smoltts_hip.h at smoltts_lm_park_slots): three steps, the first and the
+    #      last on the stream the frames run on, the middle one on any other stream once the first has run
+    def side_park(self, prompts: Sequence[np.ndarray], slots: Sequence[int]):
+        """Freeze the (idle) ``slots`` at their new prompts' last positions and upload the prompt rows; -> a handle for the two
+        steps that follow.  Call on the frame stream."""
+        slots = list(slots)
+        if len(slots) != len(prompts) or len(set(slots)) != len(slots):
+            raise ValueError("slots must be distinct and match prompts")
+        grid_d, rslot_d, rpos_d, last, n = self._rows(prompts, slots, [0] * len(prompts))
+        slots_h = (C.c_int32 * len(slots))(*slots)
+        park_h = (C.c_int32 * len(slots))(*[int(np.asarray(g).shape[1]) - 1 for g in prompts])
+        check(self.lib.smoltts_lm_park_slots(self.handle, slots_h, park_h, len(slots), current_stream_ptr()), "smoltts_lm_park_slots")
+        parked = torch.cuda.Event()
+        parked.record(torch.cuda.current_stream())
+        return {"rows": (grid_d, rslot_d, rpos_d), "n": n, "slots": slots, "last": last, "parked": parked, "done": None}
+
+    def side_run(self, h) -> None:
+        """The prompts' KV rows, on the CURRENT stream (not the frames' one); the park must have run: the host waits for it here."""
+        h["parked"].synchronize()
+        grid_d, rslot_d, rpos_d = h["rows"]
+        check(self.lib.smoltts_lm_prefill_side(self.handle, dptr(grid_d), dptr(rslot_d), dptr(rpos_d), h["n"], current_stream_ptr()),
+              "smoltts_lm_prefill_side")
+        h["done"] = torch.cuda.Event()
+        h["done"].record(torch.cuda.current_stream())
+
+    def side_start(self, h, stop_on_eos: bool = True) -> None:
+        """Arm the slots (their frame 0 comes out of the next decode frame).  Call on the frame stream; waits (host) for the side call."""
+        h["done"].synchronize()
+        grid_d, _, rpos_d = h["rows"]
+        slots_h = (C.c_int32 * len(h["slots"]))(*h["slots"])
+        last_h = (C.c_int32 * len(h["slots"]))(*h["last"])
+        check(self.lib.smoltts_lm_start_slots(self.handle, dptr(grid_d), dptr(rpos_d), slots_h, last_h, len(h["slots"]), int(stop_on_eos),
+                                              current_stream_ptr()), "smoltts_lm_start_slots")
+        self._keep = h["rows"]  # alive until the stream has consumed them
+
+    def prefill(self, prompts: Sequence[np.ndarray], slots: Optional[Sequence[int]] = None, stop_on_eos: bool = True,
+                pos0: Optional[Sequence[int]] = None, final: bool = True, defer_frame0: bool = False) -> None:
+        """prompts: one ``(1 + n_fast, T_b)`` int grid per utterance; emits frame 0 of each slot.
+
+        Chunked prefill: ``pos0[b]`` is the position of the first column of ``prompts[b]`` (its earlier columns
+        went through previous calls with ``final=False``, which fill the KV cache only and leave the slot idle).
+        ``defer_frame0``: no frame-0 tail here; the next ``decode`` call emits frame 0 as its first frame (serving loop)."""
+        slots = list(range(len(prompts))) if slots is None else list(slots)
+        if len(slots) != len(prompts) or len(set(slots)) != len(slots):
+            raise ValueError("slots must be distinct and match prompts")
+        pos0 = [0] * len(prompts) if pos0 is None else list(pos0)
+        grid_d, rslot_d, rpos_d, last, n = self._rows(prompts, slots, pos0)
         slots_h = (C.c_int32 * len(slots))(*slots)
         last_h = (C.c_int32 * len(slots))(*last)
         self._keep = (grid_d, rslot_d, rpos_d)  # alive until the stream has consumed them

@@ -59,7 +59,8 @@ class BatchScheduler:
     CODEC_BATCH, CODEC_CHUNK, CODEC_WAIT = 16, 64, 32  # slots, frames per slot and pass, LM frames a pass may wait for company
 
     def __init__(self, tts, max_batch: int = 32, frames_per_tick: int = 4, generation_settings=None, max_prompt_rows: int = 4096,
-                 prefill_chunk: Optional[int] = 128, overlap_stream_codec: bool = True):
+                 prefill_chunk: Optional[int] = 128, overlap_stream_codec: bool = True, side_prefill: bool = True,
+                 side_prefill_min_active: Optional[int] = None):
         import torch
 
         from ..config import GenerationSettings
@@ -73,6 +74,12 @@ class BatchScheduler:
         # streaming requests: the codec pass of tick k is launched on a second stream by the host once it has seen tick k finish
         # (it waits for that anyway, to read the tick's snapshot), i.e. while tick k+1 runs -- instead of in line between the ticks
         self.overlap_stream_codec = overlap_stream_codec
+        # refills while most slots are speaking: the new prompts' KV rows are computed on a second stream beside the next tick
+        # (LMSession.side_park / side_run / side_start) instead of in line between two ticks; the new tenants then start one
+        # tick later.  With few slots speaking the in-line prefill answers sooner and stops nobody worth mentioning.
+        self.side_prefill = side_prefill and __import__("os").environ.get("SMOLTTS_SIDE_PREFILL") != "0"  # (the switch of tools/bench_scheduler.py A/B runs)
+        self.side_min_active = max(1, max_batch // 2) if side_prefill_min_active is None else side_prefill_min_active
+        self._side = None  # the one refill in flight: {"h": handle, "reqs": [...], "state": "parked" | "running"}
         self.settings = generation_settings or GenerationSettings.greedy()
         self.max_frames = self.settings.max_new_tokens + 1
         self.session = LMSession(tts.lm, max_batch, max_seq=tts.config.max_seq_len, max_rows=max(max_prompt_rows, max_batch),
@@ -153,7 +160,7 @@ class BatchScheduler:
             self._draining = True
             deadline = time.time() + timeout
             while (self._thread.is_alive() and time.time() < deadline and
-                   (self._active or self._retiring or self._held is not None or not self._pending.empty() or self._codec_backlog() or self._deliveries)):
+                   (self._active or self._side is not None or self._retiring or self._held is not None or not self._pending.empty() or self._codec_backlog() or self._deliveries)):
                 time.sleep(0.01)
         self._stop.set()
         self._wake.set()
@@ -165,9 +172,52 @@ class BatchScheduler:
         self.session.close()
 
     # ------------------------------------------------------------------ worker: admission
+    def _side_advance(self) -> None:
+        """The refill in flight, one step on: parked -> its side call goes out (the host waits for the park, a few us behind the
+        tick it was queued after); running -> the slots are armed on the frame stream and the requests enter the books: their
+        frame 0 comes out of the next tick."""
+        sd = self._side
+        if sd is None:
+            return
+        if sd["state"] == "parked":
+            with self._torch.cuda.stream(self._side_stream):
+                t = time.perf_counter()
+                self.session.side_run(sd["h"])
+                self._gpu_wait_s += time.perf_counter() - t
+            sd["state"] = "running"
+            return
+        t = time.perf_counter()
+        self.session.side_start(sd["h"], stop_on_eos=True)
+        self._gpu_wait_s += time.perf_counter() - t
+        self._side = None
+        self._enter(sd["reqs"])
+
+    def _enter(self, new: List[_Request]) -> None:
+        """Requests whose slots have just been armed: codec stream bookkeeping, first / last tick, into the active set."""
+        streams = [r.slot for r in new if r.stream]
+        if streams:
+            from ..engine import MimiSession
+
+            if self._stream_codec is None:
+                self._stream_codec = MimiSession(self.tts.codec, max_batch=self.B, max_chunk_frames=max(self.tick, 1))
+                self._stream_codec.reset()
+            if not self.overlap_stream_codec:  # (overlapped: the slot's stream restarts on the codec stream, right before the pass
+                self._stream_codec.reset_slots(streams)  # of the request's first tick and behind the previous tenant's last pass)
+                for b in streams:
+                    self._codec_age[b] = 0
+        for r in new:
+            r.first_tick = self._tick_no
+            r.last_tick = self._tick_no + -(-(r.max_new_tokens + 1) // self.tick) - 1  # ceil(frames / tick) ticks from first_tick on
+            self._active[r.slot] = r
+
     def _admit(self) -> None:
+        if self._side is not None and self._side["state"] == "running":
+            self._side_advance()
         new: List[_Request] = []
         rows = 0  # prompt rows of the (first) prefill call of this admission; the session's workspace holds max_rows
+        side = self.side_prefill and self._side is None and len(self._active) >= self.side_min_active
+        if self._side is not None:
+            return  # one refill at a time: the next arrivals wait for it (at most a tick)
         if self._held is not None or not self._pending.empty():
             # A request that ends by its frame budget ends in a tick known since its admission.  Once that tick is queued the
             # slot can take its next tenant straight away: the prefill is queued behind the tick, and the snapshots (device-side
@@ -193,7 +243,13 @@ class BatchScheduler:
                 except Exception as e:  # bad request: answer it, keep serving
                     self._end(req, e)
                     continue
-            need = min(req.prompt.shape[1], self.prefill_chunk or req.prompt.shape[1])
+            need = req.prompt.shape[1] if side else min(req.prompt.shape[1], self.prefill_chunk or req.prompt.shape[1])
+            if side and need > self.session.max_rows:
+                side = False if not new else side  # a prompt too long for one side call goes in line, in chunks (alone)
+                if new:
+                    self._held = req
+                    break
+                need = min(req.prompt.shape[1], self.prefill_chunk or req.prompt.shape[1])
             if new and rows + need > self.session.max_rows:  # no room in this call: first in line next time
                 self._held = req
                 break
@@ -202,27 +258,22 @@ class BatchScheduler:
             new.append(req)
         if not new:
             return
+        if side:
+            try:
+                h = self.session.side_park([r.prompt for r in new], [r.slot for r in new])  # queued behind the ticks so far
+            except Exception as e:
+                for r in new:
+                    self._end(r, e)
+                raise
+            self._side = {"h": h, "reqs": new, "state": "parked"}
+            return
         try:
             self._prefill(new)
         except Exception as e:  # these requests are in nobody's books yet: answer them here, then let the worker fail
             for r in new:
                 self._end(r, e)
             raise
-        streams = [r.slot for r in new if r.stream]
-        if streams:
-            from ..engine import MimiSession
-
-            if self._stream_codec is None:
-                self._stream_codec = MimiSession(self.tts.codec, max_batch=self.B, max_chunk_frames=max(self.tick, 1))
-                self._stream_codec.reset()
-            if not self.overlap_stream_codec:  # (overlapped: the slot's stream restarts on the codec stream, right before the pass
-                self._stream_codec.reset_slots(streams)  # of the request's first tick and behind the previous tenant's last pass)
-                for b in streams:
-                    self._codec_age[b] = 0
-        for r in new:
-            r.first_tick = self._tick_no
-            r.last_tick = self._tick_no + -(-(r.max_new_tokens + 1) // self.tick) - 1  # ceil(frames / tick) ticks from first_tick on
-            self._active[r.slot] = r
+        self._enter(new)
 
     def _prefill(self, new: List[_Request]) -> None:
         if self.prefill_chunk:
@@ -527,10 +578,14 @@ class BatchScheduler:
             compute = torch.cuda.Stream(priority=prio)
             self._copy_stream = torch.cuda.Stream()
             self._codec_stream = torch.cuda.Stream()
+            self._side_stream = torch.cuda.Stream()
             with torch.cuda.stream(compute):
                 while not self._stop.is_set():
                     self._admit()
                     if not self._active:
+                        if self._side is not None:  # (its slots are the only ones taken: nothing to run beside)
+                            self._side_advance()
+                            continue
                         self._consume_snapshots(keep=0)
                         self._decode_finished(force=True)
                         if self._deliveries or self._codec_backlog():
@@ -554,6 +609,8 @@ class BatchScheduler:
                             self._deliver(wait=False)  # a first chunk: wait for its pass (the running tick leaves the host slack)
                     else:
                         self._consume_snapshots(keep=0 if first_chunk_due else 1)
+                    if self._side is not None and self._side["state"] == "parked":
+                        self._side_advance()  # the tick before the park has been seen to finish: the side call runs beside this one
             self._fail_all(RuntimeError("scheduler closed"))  # requests still in flight when close() was called
         except Exception as e:  # engine failure: fail every waiter loudly
             self._fail_all(e)
@@ -578,7 +635,9 @@ class BatchScheduler:
         if self._held is not None:
             self._end(self._held, e)
             self._held = None
-        for r in list(self._active.values()) + self._retiring + self._finished + [j.req for j in self._codec_jobs if j is not None]:
+        side = self._side["reqs"] if self._side is not None else []
+        self._side = None
+        for r in list(self._active.values()) + side + self._retiring + self._finished + [j.req for j in self._codec_jobs if j is not None]:
             self._end(r, e)
         self._codec_jobs = [None] * len(self._codec_jobs)
         for d in self._deliveries:
