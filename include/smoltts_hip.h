@@ -229,7 +229,7 @@ int smoltts_session_set_frames_per_graph(SmolttsSession* s, int32_t n, void* str
  *                             fp32 sums in a different order than the one-workgroup kernel: same ids except at near-ties
  *   SMOLTTS_OPT_FUSE_DEPTH_ATTN  (ABI 5) depth steps 1..: the attention over the <= 8-entry cache is worked out by the wo launch
  *                             itself (SmolttsGemm3Args.attn_q_dev) instead of by a launch of its own (default 1; applies where
- *                             smoltts_gemm3_attn_fusable); again another fp32 summation order than the stand-alone kernel */
+ *                             smoltts_gemm3_attn_fusable); every sum formed in the stand-alone kernels' order: bit-identical to them */
 #define SMOLTTS_OPT_QKV_TABLE 1
 #define SMOLTTS_OPT_COMMIT_PICKS 2
 #define SMOLTTS_OPT_SPLIT_ATTN 3
@@ -489,7 +489,8 @@ typedef struct SmolttsGemm3Args {
    * instead every workgroup works out, for the rows it multiplies, softmax(q K^T / 8) V over keys 0 .. attn_pos of the row's own
    * slot (row r == slot r) in k_cache_dev / v_cache_dev [M][n_kv_heads][cache_len][64] fp32 -- the output of
    * smoltts_k_attention for those rows -- and feeds it to the matrix cores as bf16x3 pieces through LDS.  One launch instead of
-   * two per depth layer; needs smoltts_gemm3_attn_fusable(n_q_heads, n_kv_heads, cache_len) and K == n_q_heads * 64. */
+   * two per depth layer, with the same bits (every sum in the order smoltts_k_attention + this launch without the prologue form it, at
+ * up to 128 rows); needs smoltts_gemm3_attn_fusable(n_q_heads, n_kv_heads, cache_len) and K == n_q_heads * 64. */
   const float* attn_q_dev;     /* fp32 [M][n_q_heads*64] (RoPE applied: the q rows an EPI_QKV_ROPE launch wrote) */
   int32_t attn_pos;
 } SmolttsGemm3Args;

@@ -508,9 +508,12 @@ __global__ __launch_bounds__(256) void gemm3_rows_kernel(Gemm3Dev p) {
 //            its <= 2 keys, merged over the 4 key groups (row_ror:8, then lane ^ 16); the weighted V sums travel the same two
 //            steps, each lane handing over the half it does not publish.  Each lane ends up with 2 output values, splits them
 //            into bf16x3 and writes them to LDS in the MFMA B-fragment order of x3.h (R rows instead of 16 per chunk).
-//   phase B  the other eight waves, which have had the whole weight stream in flight meanwhile (chunk c belongs to GEMM wave c % 8), take the B fragments from LDS, run all the MFMAs and leave their partial tiles in LDS; the
+//   phase B  the other eight waves, which have had the whole weight stream in flight meanwhile (chunk c belongs to GEMM wave c % nb, nb = gemm3_kernel's wave count for this K: 8 at K = 768), take the B fragments from LDS, run all the MFMAs and leave their partial tiles in LDS; the
 //            epilogue of gemm3_kernel's RESID case (fixed-order sum of the four partials, residual, fp32 store, X3 emission,
 //            partial sums of squares) runs on waves 0 .. T-1, whose inputs were requested before phase A.
+// Every sum is formed in the order attn_short_kernel + gemm3_kernel<1, 1, 3, RESID> form it (the same 4-term FMA chains and
+// butterfly over the 16 partial dot products, keys j and j + 4 per lane group, the key groups merged (0 + 1) + (2 + 3), IEEE
+// division, chunk c on K part c % nb, partial tiles added in part order): the launch is BIT-IDENTICAL to the two it replaces.
 // Reference: Attention.forward (modeling/model/rq_transformer.py:535-570) at decode time inside forward_generate_fast
 // (mlx_inference/src/smoltts_mlx/lm/rq_transformer.py:194-220, 281-295).
 __device__ __forceinline__ float dpp_ror8(float x) {  // lane i of a 16-lane row <- lane i ^ 8
@@ -531,12 +534,16 @@ __device__ __forceinline__ void swap16(float& a, float& b) {
   a = __uint_as_float(r[0]);
   b = __uint_as_float(r[1]);
 }
-__device__ __forceinline__ float dot8(float4 a, float4 b, float4 k0, float4 k1) {
-  float d0 = a.x * k0.x, d1 = a.y * k0.y;  // two chains: the compiler packs them (v_pk_fma_f32)
-  d0 = fmaf(a.z, k0.z, d0); d1 = fmaf(a.w, k0.w, d1);
-  d0 = fmaf(b.x, k1.x, d0); d1 = fmaf(b.y, k1.y, d1);
-  d0 = fmaf(b.z, k1.z, d0); d1 = fmaf(b.w, k1.w, d1);
-  return d0 + d1;
+// q . k over the lane's two float4: the same two 4-term FMA chains attn_short_kernel's lanes dl = m and dl = 8 + m run
+__device__ __forceinline__ void dot4x2(float4 a, float4 b, float4 k0, float4 k1, float& lo, float& hi) {
+  lo = a.x * k0.x; lo = fmaf(a.y, k0.y, lo); lo = fmaf(a.z, k0.z, lo); lo = fmaf(a.w, k0.w, lo);
+  hi = b.x * k1.x; hi = fmaf(b.y, k1.y, hi); hi = fmaf(b.z, k1.z, hi); hi = fmaf(b.w, k1.w, hi);
+}
+// ... and the same tree over the 16 partial sums: row16_sum = (dims 0..31 over lanes 0..7) + (dims 32..63 over lanes 8..15)
+__device__ __forceinline__ float score16(float4 a, float4 b, float4 k0, float4 k1) {
+  float lo, hi;
+  dot4x2(a, b, k0, k1, lo, hi);
+  return row8_sum(lo) + row8_sum(hi);
 }
 
 #ifndef SMOLTTS_DBG_AWO_ORDER  // 0 (timing experiments): the GEMM waves start their weight stream at once
@@ -581,6 +588,11 @@ __device__ __forceinline__ void awo_load(AwoUnit<G, TWO>& u, const Gemm3Dev& p, 
 
 template <int G, bool TWO>
 __device__ __forceinline__ void awo_compute(const AwoUnit<G, TWO>& u, char* frag, int lane) {
+  // No contraction of this function's products into later additions (written as plain `*` HERE: `__fmul_rn` is a header function
+  // whose product carries the header's contraction flag, and the compiler did re-use the unrounded product inside the bf16x3
+  // split's subtractions -- the pieces then summed to a neighbour of the fp32 value attn_short_kernel rounds to, one ulp off in
+  // ~10 % of the outputs).  Explicit fmaf calls stay fused multiply-adds.
+#pragma clang fp contract(off)
   constexpr int R = AWO_R;
   const int hb = (lane >> 3) & 1, m8 = lane & 7;
   const bool up = (lane & 16) != 0;
@@ -588,10 +600,10 @@ __device__ __forceinline__ void awo_compute(const AwoUnit<G, TWO>& u, char* frag
   for (int g = 0; g < G; ++g) {
     const float4 a = make_float4(u.qa[g].x * 0.125f, u.qa[g].y * 0.125f, u.qa[g].z * 0.125f, u.qa[g].w * 0.125f);
     const float4 b = make_float4(u.qb[g].x * 0.125f, u.qb[g].y * 0.125f, u.qb[g].z * 0.125f, u.qb[g].w * 0.125f);
-    float s0 = row8_sum(dot8(a, b, u.ka0, u.kb0)), s1 = -INFINITY;
+    float s0 = score16(a, b, u.ka0, u.kb0), s1 = -INFINITY;
     s0 = u.ok0 ? s0 : -INFINITY;
     if (TWO) {
-      s1 = row8_sum(dot8(a, b, u.ka1, u.kb1));
+      s1 = score16(a, b, u.ka1, u.kb1);
       s1 = u.ok1 ? s1 : -INFINITY;
     }
     float mx = TWO ? fmaxf(s0, s1) : s0;
@@ -603,6 +615,7 @@ __device__ __forceinline__ void awo_compute(const AwoUnit<G, TWO>& u, char* frag
     }
     const float e0 = __expf(s0 - mx);    // exp(-inf) = 0: keys behind the row's position drop out by themselves
     float den = e0;
+    // (rounded products, as attn_short_kernel's fmaf(e, v, 0): this scope does not contract them into the adds below)
     float4 oa = make_float4(e0 * u.va0.x, e0 * u.va0.y, e0 * u.va0.z, e0 * u.va0.w);
     float4 ob = make_float4(e0 * u.vb0.x, e0 * u.vb0.y, e0 * u.vb0.z, e0 * u.vb0.w);
     if (TWO) {
@@ -623,9 +636,8 @@ __device__ __forceinline__ void awo_compute(const AwoUnit<G, TWO>& u, char* frag
     // moves the lower lane's z to the upper and the upper lane's x to the lower, after which x + z is what the lane publishes
     swap16(oa.x, oa.z);
     swap16(oa.y, oa.w);
-    float inv = __builtin_amdgcn_rcpf(den);
-    inv = fmaf(fmaf(-den, inv, 1.0f), inv, inv);  // one Newton step: within an ulp of 1 / den
-    const float ox = (oa.x + oa.z) * inv, oy = (oa.y + oa.w) * inv;
+    const float inv = 1.0f / den;
+    const float ox = (oa.x + oa.z) * inv, oy = (oa.y + oa.w) * inv;  // (plain products: this scope does not contract; __fmul_rn's would)
     uint32_t h, mm, l;
     split3_pair(ox, oy, h, mm, l);
     const int c = 2 * (u.kvc * G + g) + hb;  // chunk: head, half of its 64 dims
@@ -649,6 +661,8 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(Gemm3Dev p) {
   const int r = lane & 15, q = lane >> 4;
   const int ng = blockIdx.x, row0 = blockIdx.y * R;
   const int nchunks = p.K >> 5;
+  // K parts: as many as gemm3_kernel has waves for this K (launch3_fmt), so that the partial sums are the same numbers
+  const int nb = (nchunks + 2) / 3 < 1 ? 1 : ((nchunks + 2) / 3 > NB ? NB : (nchunks + 2) / 3);
   char* frag = reinterpret_cast<char*>(smem);  // [chunk][piece][q][row] x 16 B
   float4* red4 = reinterpret_cast<float4*>(frag + (size_t)nchunks * 3 * 4 * R * 16);  // [GEMM wave][tile][lane]
   STAMP3(0);
@@ -695,12 +709,18 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(Gemm3Dev p) {
     __syncthreads();  // the GEMM waves' partial tiles are in LDS
     STAMP3(3);
     if (!fin) return;
-    float4 part[NB];
+    float4 part[NB];  // (gemm3_kernel's reduction, term for term)
 #pragma unroll
-    for (int w = 0; w < NB; ++w) part[w] = red4[(w * T + tf) * 64 + lane];
+    for (int w = 0; w < NB; ++w) part[w] = red4[((w < nb ? w : 0) * T + tf) * 64 + lane];
     float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < NB; ++w) { v[0] += part[w].x; v[1] += part[w].y; v[2] += part[w].z; v[3] += part[w].w; }
+    for (int w = 0; w < NB; ++w) {
+      const bool on = w < nb;
+      v[0] += on ? part[w].x : 0.f;
+      v[1] += on ? part[w].y : 0.f;
+      v[2] += on ? part[w].z : 0.f;
+      v[3] += on ? part[w].w : 0.f;
+    }
     const int ntile = ng * T + tf;
     const int n0 = ntile * 16 + q * 4;
     const bool valid = mvalid && n0 < p.N;
@@ -730,11 +750,11 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(Gemm3Dev p) {
   uint4 wf[U][T];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const int c = gw + u * NB;
+    const int c = gw + u * nb;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int ntile = ng * T + t;
-      wf[u][t] = (c < nchunks && ntile * 16 < p.N) ? load_wfrag<W8, false>(p.w + ((size_t)ntile * nchunks + c) * WTILE + lane * WLANE)
+      wf[u][t] = (gw < nb && c < nchunks && ntile * 16 < p.N) ? load_wfrag<W8, false>(p.w + ((size_t)ntile * nchunks + c) * WTILE + lane * WLANE)
                                                    : make_uint4(0, 0, 0, 0);
     }
   }
@@ -746,8 +766,8 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(Gemm3Dev p) {
   for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const int c = gw + u * NB;
-    if (c < nchunks) {  // wave-uniform
+    const int c = gw + u * nb;
+    if (gw < nb && c < nchunks) {  // wave-uniform
       const char* fp = frag + ((size_t)((c * 3) * 4 + q) * R + (r & (R - 1))) * 16;
       uint4 xb[3];
 #pragma unroll

@@ -1,5 +1,5 @@
 """Which kernel runs depends on the batch and on the context: the key-split slow attention only for <= 128 (row, kv
-head) pairs and rows of >= 512 keys, one or three column tiles per workgroup in the fused depth attention by row count, the codec's
+head) pairs and rows of >= 512 keys, the many-row GEMM kernels above 128 rows, the codec's
 bf16x3 chunk attention only for chunks of whole groups of 32 rows per slot.  Every variant sums in fp32, in its own order, so an
 utterance's numbers may differ in the last bits with its co-tenants -- NOT a bit-exactness guarantee across batch compositions
 (INTEGRATION.md says so).  What is guaranteed is the parity contract of DESIGN.md section 2: ids differ only where the oracle's own top-2
