@@ -234,6 +234,9 @@ int smoltts_session_set_frames_per_graph(SmolttsSession* s, int32_t n, void* str
 #define SMOLTTS_OPT_COMMIT_PICKS 2
 #define SMOLTTS_OPT_SPLIT_ATTN 3
 #define SMOLTTS_OPT_FUSE_DEPTH_ATTN 5
+#define SMOLTTS_OPT_FUSE_PICK 6  /* (ABI 5) greedy depth codes picked inside the next step's layer-0 attention + wo launch (SmolttsPickArgs)
+                                    instead of by a launch of their own (default 1; needs the fast_qkv table, the fused depth
+                                    attention and greedy depth tokens); same ids, same gap records */
 #define SMOLTTS_OPT_STREAM_W 4  /* value = mask of SMOLTTS_STREAM_W_*: which weights of a decode frame are loaded with the non-temporal
                                   hint (read once per frame: keeping them out of the caches leaves room for the depth layers'
                                   weights, which are re-read for each of the 8 depth steps) */
@@ -493,7 +496,35 @@ typedef struct SmolttsGemm3Args {
  * up to 128 rows); needs smoltts_gemm3_attn_fusable(n_q_heads, n_kv_heads, cache_len) and K == n_q_heads * 64. */
   const float* attn_q_dev;     /* fp32 [M][n_q_heads*64] (RoPE applied: the q rows an EPI_QKV_ROPE launch wrote) */
   int32_t attn_pos;
+  /* EPI_STORE (ABI 5): also leave, for every (row, 16-column tile) of the result, the tile's largest value, the first column that
+   * holds it (int32 bits) and the runner-up: float [M][ceil(N/16)][4] (4th unused) -- what a greedy pick needs of a row of logits */
+  float* cand_out_dev;
+  /* the attention prologue with the PICK in front of it (ABI 5; NULL = off): the rows are depth step attn_pos of a frame whose
+   * previous head GEMM left cand_out_dev; see SmolttsPickArgs.  attn_q_dev and resid_dev are then not read. */
+  const struct SmolttsPickArgs* pick;
 } SmolttsGemm3Args;
+
+/* Greedy pick of the previous depth step's code inside the launch that consumes it (depth layer 0 of the next step, whose q | k | v
+ * come out of the engine's fast_qkv table): every workgroup merges its rows' tile candidates (first maximal column, as
+ * torch.argmax), gathers q and the new key's K / V rows of the picked embedding row from the table (RoPE for attn_pos applied on the
+ * way, bit-identical to the stand-alone picking kernel's), takes the residual row from the embedding table, and runs attention + wo
+ * as with attn_q_dev.  The workgroups of column group 0 also record the id, the top-2 gap bookkeeping of smoltts_k_argmax and the
+ * new K / V cache rows.  One launch fewer per depth step (lm/generate.py:118-141). */
+typedef struct SmolttsPickArgs {
+  const float* cand_dev;          /* [M][cand_tiles][4] from the head GEMM's cand_out_dev */
+  int32_t cand_tiles;             /* codebook_size / 16 */
+  const float* qkv_table_dev;     /* fp32 [emb rows][(n_q_heads + 2 n_kv_heads) * 64], before RoPE */
+  const float* rope_dev;          /* fp32 [pos][32][2] */
+  const void* emb_dev;            /* bf16 [emb rows][K]: the residual row of a picked id */
+  int32_t emb_row_offset;         /* embedding / table row = id + emb_row_offset (depthwise tables: lm/generate.py:136-140) */
+  int32_t* ids_dev;               /* row r's id -> ids_dev[r * ids_stride] */
+  int32_t ids_stride;
+  float* margin_dev;              /* [M] smallest top-2 gap so far (updated where margin_mask_dev[r] != 0), or NULL */
+  const int32_t* margin_mask_dev;
+  int32_t* margin_at_dev;         /* [M] frames_dev[r] * 64 + step of that gap, or NULL */
+  const int32_t* frames_dev;
+  int32_t step;
+} SmolttsPickArgs;
 
 /* 1 when the attention prologue above exists for this head layout (<= 12 query heads, groups of <= 4 per kv head, <= 8 cache entries) */
 int smoltts_gemm3_attn_fusable(int32_t n_q_heads, int32_t n_kv_heads, int32_t cache_len);

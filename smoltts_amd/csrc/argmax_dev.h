@@ -152,6 +152,16 @@ struct QkvGather {
 
 // The row's q | k | v: loaded by `qkv_gather_load` (up to QG_MAX float4 per thread, all requested at once, together with the RoPE
 // rows they need -- a loop over the row would be one dependent L2 round trip per iteration), finished by `qkv_gather_store`.
+// RoPE of the two (even, odd) pairs of a float4 of table values: rounded products, rounded sums (no contraction) -- the one
+// place that defines these bits, shared by the picking kernel's gather (small_ops.hip) and by the pick inside the attention + wo
+// launch (gemm3.hip attn_wo_kernel), which must publish the same q / K rows.
+__device__ __forceinline__ float4 rope_gathered4(float4 v, float4 cs) {
+#pragma clang fp contract(off)
+  const float o0 = v.x * cs.x - v.y * cs.y, o1 = v.y * cs.x + v.x * cs.y;
+  const float o2 = v.z * cs.z - v.w * cs.w, o3 = v.w * cs.z + v.z * cs.w;
+  return make_float4(o0, o1, o2, o3);
+}
+
 constexpr int QG_MAX = 2;  // 256 threads x 2 x 4 floats = rows of up to 2048 values (150m: 1280); longer rows take more rounds
 struct QkvRegs { float4 v[QG_MAX], cs[QG_MAX]; };
 
@@ -173,12 +183,7 @@ __device__ __forceinline__ void qkv_gather_store(const QkvGather& g, int r, int 
     const int n0 = base + (threadIdx.x + i * 256) * 4;
     if (n0 >= nqkv) continue;
     float4 v = in.v[i];
-    if (n0 < qd + kd) {
-      const float4 cs = in.cs[i];
-      const float o0 = v.x * cs.x - v.y * cs.y, o1 = v.y * cs.x + v.x * cs.y;
-      const float o2 = v.z * cs.z - v.w * cs.w, o3 = v.w * cs.z + v.z * cs.w;
-      v = make_float4(o0, o1, o2, o3);
-    }
+    if (n0 < qd + kd) v = rope_gathered4(v, in.cs[i]);
     if (n0 < qd) {
       *reinterpret_cast<float4*>(g.q_out + (long)r * qd + n0) = v;
     } else {

@@ -22,7 +22,7 @@
 // sums of squares (wo / w2), the SwiGLU product as X3 (w1|w3), RoPE'd q + KV-cache rows (wqkv).
 #include <stdlib.h>
 
-#include "x3.h"
+#include "argmax_dev.h"  // Top2 / top2_merge / rope_gathered4 (and x3.h)
 #ifndef SMOLTTS_DBG_PIECES
 #define SMOLTTS_DBG_PIECES 3
 #endif
@@ -55,6 +55,13 @@ struct Gemm3Dev {
   int kv_bf16;
   char* v_x3;  // QKV_ROPE, rows at position 0: attention over one key is V itself -> V published as wo's X3 operand
   int n_q_heads, n_kv_heads, cache_len;
+  float* cand;      // EPI_STORE: per (row, 16-column tile) (max, first column of it, runner-up, -) for a later pick; nullptr = off
+  // attn_wo_kernel<.., PICK>: the previous depth step's code picked in front of the attention (SmolttsPickArgs)
+  const float* pk_cand; int pk_tiles;
+  const float* pk_table; const float* pk_rope;
+  const uint16_t* pk_emb; int pk_off;
+  int* pk_ids; int pk_ids_stride;
+  float* pk_margin; const int* pk_mask; int* pk_margin_at; const int* pk_frames; int pk_step;
   const float* aq;  // attn_wo_kernel: q rows [M][n_q_heads * 64] of the attention recomputed in front of the K loop ...
   int a_pos;        // ... every row r being slot r at this position of the <= 8-entry caches kc / vc (a depth step)
   unsigned long long* stamps;  // diagnostics only (smoltts_debug_set_stamps); nullptr in production
@@ -315,6 +322,24 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
         sq += __shfl_xor(sq, 32);
         if (q == 0 && mvalid && ntile * 16 < p.N) p.emit.ssq[(size_t)m * (p.N >> 4) + ntile] = sq;
       }
+      if (EPI == SMOLTTS_EPI_STORE && p.cand) {  // (wave-uniform) the tile's top-2 per row: what a greedy pick needs of these logits
+        Top2 t{-INFINITY, 0x7fffffff, -INFINITY};
+        if (valid) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (v[i] > t.v1) { t.v2 = t.v1; t.v1 = v[i]; t.i1 = n0 + i; }  // strictly greater: the first of equal columns stays
+            else if (v[i] > t.v2) t.v2 = v[i];
+          }
+        }
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {  // the 4 lanes (q) that hold the row's 16 columns
+          Top2 b;
+          b.v1 = __shfl_xor(t.v1, o); b.i1 = __shfl_xor(t.i1, o); b.v2 = __shfl_xor(t.v2, o);
+          t = top2_merge(t, b);
+        }
+        if (q == 0 && mvalid && ntile * 16 < p.N)
+          *reinterpret_cast<float4*>(p.cand + ((size_t)m * ((p.N + 15) >> 4) + ntile) * 4) = make_float4(t.v1, __int_as_float(t.i1), t.v2, 0.f);
+      }
     } else if (EPI == SMOLTTS_EPI_SWIGLU) {
       if (valid) x3_emit2(p.x3_out, m, n0 >> 1, p.N >> 6, silu3(v[0]) * v[1], silu3(v[2]) * v[3]);
     } else if (EPI == SMOLTTS_EPI_QKV_ROPE) {
@@ -559,8 +584,12 @@ struct AwoUnit {
   bool hv, ok0, ok1;
 };
 
-template <int G, bool TWO>
-__device__ __forceinline__ void awo_load(AwoUnit<G, TWO>& u, const Gemm3Dev& p, int unit, int kv_pairs, int row0, int lane) {
+// PICK (erow is then the row of the engine's q | k | v table picked for this row, SmolttsPickArgs): q and the NEWEST key's K / V
+// (key a_pos) come out of that table row instead of the q buffer / the cache, RoPE for position a_pos applied here with the
+// picking kernel's own arithmetic (rope_gathered4); `write_kv`: this workgroup also puts the new K / V rows into the cache.
+template <int G, bool TWO, bool PICK>
+__device__ __forceinline__ void awo_load(AwoUnit<G, TWO>& u, const Gemm3Dev& p, int unit, int kv_pairs, int row0, int lane, long erow = 0,
+                                         bool write_kv = false) {
   const int kq = lane >> 5, jj = (lane >> 3) & 3, hb = jj & 1, m8 = lane & 7;
   const int L = p.a_pos + 1;  // keys 0 .. a_pos
   u.rl = unit / kv_pairs;
@@ -571,19 +600,91 @@ __device__ __forceinline__ void awo_load(AwoUnit<G, TWO>& u, const Gemm3Dev& p, 
   u.ok0 = jj < L;
   u.ok1 = TWO && jj + 4 < L;
   const long o0 = cb + (long)(u.ok0 ? jj : 0) * 64, o1 = cb + (long)(u.ok1 ? jj + 4 : 0) * 64;
+  const float *k0p = p.kc + o0, *v0p = p.vc + o0, *k1p = p.kc + o1, *v1p = p.vc + o1;
+  const int qd = p.n_q_heads * 64, kd = p.n_kv_heads * 64;
+  const float* trow = PICK ? p.pk_table + erow * (qd + 2 * kd) : nullptr;
+  const bool new0 = PICK && jj == p.a_pos, new1 = PICK && TWO && jj + 4 == p.a_pos;  // this lane's key is the row's own (newest) one
+  if (PICK) {
+    const float *tk = trow + qd + u.kvc * 64 + 4 * m8, *tv = trow + qd + kd + u.kvc * 64 + 4 * m8;
+    if (new0) { k0p = tk; v0p = tv; }
+    if (new1) { k1p = tk; v1p = tv; }
+  }
   // K: dims [4m, +4) and [32 + 4m, +4); V: the half this lane publishes (hb) first, the other half second
-  u.ka0 = *reinterpret_cast<const float4*>(p.kc + o0); u.kb0 = *reinterpret_cast<const float4*>(p.kc + o0 + 32);
-  u.va0 = *reinterpret_cast<const float4*>(p.vc + o0 + 32 * hb); u.vb0 = *reinterpret_cast<const float4*>(p.vc + o0 + 32 * (1 - hb));
+  u.ka0 = *reinterpret_cast<const float4*>(k0p); u.kb0 = *reinterpret_cast<const float4*>(k0p + 32);
+  u.va0 = *reinterpret_cast<const float4*>(v0p + 32 * hb); u.vb0 = *reinterpret_cast<const float4*>(v0p + 32 * (1 - hb));
   if (TWO) {
-    u.ka1 = *reinterpret_cast<const float4*>(p.kc + o1); u.kb1 = *reinterpret_cast<const float4*>(p.kc + o1 + 32);
-    u.va1 = *reinterpret_cast<const float4*>(p.vc + o1 + 32 * hb); u.vb1 = *reinterpret_cast<const float4*>(p.vc + o1 + 32 * (1 - hb));
+    u.ka1 = *reinterpret_cast<const float4*>(k1p); u.kb1 = *reinterpret_cast<const float4*>(k1p + 32);
+    u.va1 = *reinterpret_cast<const float4*>(v1p + 32 * hb); u.vb1 = *reinterpret_cast<const float4*>(v1p + 32 * (1 - hb));
   }
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    const float* qp = p.aq + (long)row * (p.n_q_heads * 64) + (u.kvc * G + g) * 64 + 4 * m8;
+    const float* qp = PICK ? trow + (u.kvc * G + g) * 64 + 4 * m8 : p.aq + (long)row * qd + (u.kvc * G + g) * 64 + 4 * m8;
     u.qa[g] = *reinterpret_cast<const float4*>(qp);
     u.qb[g] = *reinterpret_cast<const float4*>(qp + 32);
   }
+  if (PICK) {
+    // RoPE rows of position a_pos for the lane's dims: (4m, 4m+1), (4m+2, 4m+3) and the same 32 dims on
+    const float4 csa = *reinterpret_cast<const float4*>(p.pk_rope + ((long)p.a_pos * 32 + 2 * m8) * 2);
+    const float4 csb = *reinterpret_cast<const float4*>(p.pk_rope + ((long)p.a_pos * 32 + 16 + 2 * m8) * 2);
+#pragma unroll
+    for (int g = 0; g < G; ++g) { u.qa[g] = rope_gathered4(u.qa[g], csa); u.qb[g] = rope_gathered4(u.qb[g], csb); }
+    const float4 ra0 = rope_gathered4(u.ka0, csa), rb0 = rope_gathered4(u.kb0, csb);
+    if (new0) { u.ka0 = ra0; u.kb0 = rb0; }
+    if (TWO) {
+      const float4 ra1 = rope_gathered4(u.ka1, csa), rb1 = rope_gathered4(u.kb1, csb);
+      if (new1) { u.ka1 = ra1; u.kb1 = rb1; }
+    }
+    if (write_kv && u.hv && (new0 || new1)) {  // the cache rows later steps attend to (what the picking kernel's gather writes)
+      float* kw = p.kc + cb + (long)p.a_pos * 64;
+      float* vw = p.vc + cb + (long)p.a_pos * 64;
+      const float4 ka = new0 ? u.ka0 : u.ka1, kb = new0 ? u.kb0 : u.kb1, va = new0 ? u.va0 : u.va1, vb = new0 ? u.vb0 : u.vb1;
+      *reinterpret_cast<float4*>(kw) = ka; *reinterpret_cast<float4*>(kw + 32) = kb;
+      *reinterpret_cast<float4*>(vw + 32 * hb) = va; *reinterpret_cast<float4*>(vw + 32 * (1 - hb)) = vb;
+    }
+  }
+}
+
+// The picked id of one row from the head GEMM's tile candidates (Gemm3Dev.cand layout), by a whole wave: every lane returns it.
+// The merge across lanes stays on the VALU (DPP inside 16-lane rows, v_permlane16/32_swap across them): six dependent
+// ds_bpermute round trips per row -- what __shfl_xor compiles to -- were most of what the pick added to the launch.
+template <int CTRL>
+__device__ __forceinline__ Top2 top2_dpp(Top2 t) {
+  Top2 b;
+  b.v1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t.v1), CTRL, 0xF, 0xF, true));
+  b.i1 = __builtin_amdgcn_update_dpp(0, t.i1, CTRL, 0xF, 0xF, true);
+  b.v2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t.v2), CTRL, 0xF, 0xF, true));
+  return top2_merge(t, b);
+}
+template <bool ROWS32>
+__device__ __forceinline__ Top2 top2_swap(Top2 t, int lane) {  // partner = lane ^ 16 (ROWS32: lane ^ 32)
+  const unsigned a[3] = {__float_as_uint(t.v1), (unsigned)t.i1, __float_as_uint(t.v2)};
+  unsigned o[3];
+  const bool upper = (lane & (ROWS32 ? 32 : 16)) != 0;  // after swap(x, x): the lower lane's partner value is result 1, the upper's result 0
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (ROWS32) {
+      const auto r = __builtin_amdgcn_permlane32_swap(a[i], a[i], false, false);
+      o[i] = upper ? r[0] : r[1];
+    } else {
+      const auto r = __builtin_amdgcn_permlane16_swap(a[i], a[i], false, false);
+      o[i] = upper ? r[0] : r[1];
+    }
+  }
+  return top2_merge(t, Top2{__uint_as_float(o[0]), (int)o[1], __uint_as_float(o[2])});
+}
+__device__ __forceinline__ Top2 awo_pick_row(const float* cand, int tiles, int lane) {
+  Top2 t{-INFINITY, 0x7fffffff, -INFINITY};
+  for (int j = lane; j < tiles; j += 64) {
+    const float4 c = *reinterpret_cast<const float4*>(cand + (size_t)j * 4);
+    t = top2_merge(t, Top2{c.x, __float_as_int(c.y), c.z});
+  }
+  t = top2_dpp<0xB1>(t);   // lane ^ 1
+  t = top2_dpp<0x4E>(t);   // lane ^ 2
+  t = top2_dpp<0x141>(t);  // the other quad of the half row
+  t = top2_dpp<0x140>(t);  // the other half row
+  t = top2_swap<false>(t, lane);
+  t = top2_swap<true>(t, lane);
+  return t;
 }
 
 template <int G, bool TWO>
@@ -652,7 +753,7 @@ __device__ __forceinline__ void awo_compute(const AwoUnit<G, TWO>& u, char* frag
 
 constexpr int AWO_NA = 4, AWO_NB = 8, AWO_U = 3;  // attention waves, GEMM waves, 32-k chunks per GEMM wave (K <= 768)
 
-template <int G, int T, bool TWO, bool W8>  // TWO: more than 4 keys (a second key per lane)
+template <int G, int T, bool TWO, bool W8, bool PICK>  // TWO: more than 4 keys (a second key per lane); PICK: SmolttsPickArgs
 __global__ __launch_bounds__(768) void attn_wo_kernel(Gemm3Dev p) {
   constexpr int WTILE = W8 ? 512 : 1024, WLANE = W8 ? 8 : 16;
   constexpr int R = AWO_R, NA = AWO_NA, NB = AWO_NB, U = AWO_U;
@@ -674,8 +775,36 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(Gemm3Dev p) {
   if (wave < NA) {
     const int kv_pairs = (p.n_kv_heads + 1) >> 1;
     const int n_units = (p.M - row0 < R ? p.M - row0 : R) * kv_pairs;  // (row, kv pair) units of this workgroup: wave, wave + NA, ..
+    // PICK: the previous step's code of both rows, by every attention wave (the candidates are 2 KB per row, and the finishing
+    // waves need both rows' embedding rows): id -> row of the embedding / q | k | v tables
+    long erow0 = 0, erow1 = 0;
+    if (PICK) {
+      const int n_cols = p.pk_tiles * 16;
+      Top2 t0 = awo_pick_row(p.pk_cand + (size_t)row0 * p.pk_tiles * 4, p.pk_tiles, lane), t1 = t0;
+      if (row0 + 1 < p.M) t1 = awo_pick_row(p.pk_cand + (size_t)(row0 + 1) * p.pk_tiles * 4, p.pk_tiles, lane);
+      if (t0.i1 < 0 || t0.i1 >= n_cols) t0.i1 = 0;  // all-NaN row: stay inside the tables (argmax_row does the same)
+      if (t1.i1 < 0 || t1.i1 >= n_cols) t1.i1 = 0;
+      erow0 = (long)t0.i1 + p.pk_off;
+      erow1 = (long)t1.i1 + p.pk_off;
+      if (blockIdx.x == 0 && wave == 0 && lane == 0) {  // the records of the picking kernel (argmax_row), once per row
+#pragma unroll
+        for (int rl = 0; rl < R; ++rl) {
+          const int row = row0 + rl;
+          if (row >= p.M) break;
+          const Top2 t = rl ? t1 : t0;
+          p.pk_ids[(long)row * p.pk_ids_stride] = t.i1;
+          if (p.pk_margin && (p.pk_mask == nullptr || p.pk_mask[row])) {
+            const float gap = t.v1 - t.v2;
+            if (gap < p.pk_margin[row]) {
+              p.pk_margin[row] = gap;
+              if (p.pk_margin_at) p.pk_margin_at[row] = p.pk_frames[row] * 64 + p.pk_step;
+            }
+          }
+        }
+      }
+    }
     AwoUnit<G, TWO> un;
-    if (wave < n_units) awo_load(un, p, wave, kv_pairs, row0, lane);
+    if (wave < n_units) awo_load<G, TWO, PICK>(un, p, wave, kv_pairs, row0, lane, wave / kv_pairs ? erow1 : erow0, blockIdx.x == 0);
     // epilogue inputs of the finishing waves (wave f: column tile f): in flight across phase A, the barriers and the K loop
     const bool fin = wave < T;
     const int tf = fin ? wave : 0;
@@ -690,7 +819,12 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(Gemm3Dev p) {
       const int n0r = (ng * T + tf) * 16 + q * 4;
       const int n0 = n0r < p.N ? n0r : p.N - 4;  // N % 4 == 0
       if (W8) ws = *reinterpret_cast<const float4*>(p.wscale + n0);
-      rr = *reinterpret_cast<const float4*>(p.resid + (long)mc * p.ldo + n0);
+      if (PICK) {  // the residual row is the picked code's embedding row (bf16, widened exactly: what the picking kernel stores as x)
+        const uint2 e = *reinterpret_cast<const uint2*>(p.pk_emb + ((r & 1) ? erow1 : erow0) * p.K + n0);
+        rr = make_float4(bf16_lo(e.x), bf16_hi(e.x), bf16_lo(e.y), bf16_hi(e.y));
+      } else {
+        rr = *reinterpret_cast<const float4*>(p.resid + (long)mc * p.ldo + n0);
+      }
       if (p.bias != nullptr) bb = *reinterpret_cast<const float4*>(p.bias + n0);
       if (p.emit.x3a && p.emit.gamma_a) ga = *reinterpret_cast<const float4*>(p.emit.gamma_a + n0);
       if (p.emit.x3b && p.emit.gamma_b) gb = *reinterpret_cast<const float4*>(p.emit.gamma_b + n0);
@@ -701,7 +835,7 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(Gemm3Dev p) {
 #endif
     if (wave < n_units) awo_compute(un, frag, lane);
     for (int unit = wave + NA; unit < n_units; unit += NA) {  // (more than 2 x NA / R kv heads: no shipped config)
-      awo_load(un, p, unit, kv_pairs, row0, lane);
+      awo_load<G, TWO, PICK>(un, p, unit, kv_pairs, row0, lane, unit / kv_pairs ? erow1 : erow0, blockIdx.x == 0);
       awo_compute(un, frag, lane);
     }
     STAMP3(6);
@@ -800,13 +934,15 @@ static int launch_attn_wo_g(const Gemm3Dev& d, hipStream_t stream) {
   const size_t lds = (size_t)nchunks * 3 * 4 * AWO_R * 16 + (size_t)AWO_NB * T * 1024;
   const bool two = d.a_pos + 1 > 4;
   const dim3 block((AWO_NA + AWO_NB) * 64);
-  if (T == 3) {
-    if (two) hipLaunchKernelGGL((attn_wo_kernel<G, 3, true, W8>), grid, block, lds, stream, d);
-    else hipLaunchKernelGGL((attn_wo_kernel<G, 3, false, W8>), grid, block, lds, stream, d);
+#define ST_AWO(TT, TWO_, PK_) hipLaunchKernelGGL((attn_wo_kernel<G, TT, TWO_, W8, PK_>), grid, block, lds, stream, d)
+  if (d.pk_cand) {
+    if (T == 3) { if (two) ST_AWO(3, true, true); else ST_AWO(3, false, true); }
+    else { if (two) ST_AWO(1, true, true); else ST_AWO(1, false, true); }
   } else {
-    if (two) hipLaunchKernelGGL((attn_wo_kernel<G, 1, true, W8>), grid, block, lds, stream, d);
-    else hipLaunchKernelGGL((attn_wo_kernel<G, 1, false, W8>), grid, block, lds, stream, d);
+    if (T == 3) { if (two) ST_AWO(3, true, false); else ST_AWO(3, false, false); }
+    else { if (two) ST_AWO(1, true, false); else ST_AWO(1, false, false); }
   }
+#undef ST_AWO
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
 }
@@ -907,7 +1043,7 @@ int launch_gemm3(const SmolttsGemm3Args& a, hipStream_t stream) {
 static int launch_gemm3_impl(const SmolttsGemm3Args& a, hipStream_t stream) {
   ST_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 32 == 0 && a.N % 4 == 0, SMOLTTS_E_INVALID,
              "gemm3: bad shape M=%d N=%d K=%d (K %% 32, N %% 4)", a.M, a.N, a.K);
-  ST_REQUIRE(a.w_dev && (a.x3_dev || (a.attn_q_dev && a.epilogue == SMOLTTS_EPI_RESID)), SMOLTTS_E_INVALID, "gemm3: null operand");
+  ST_REQUIRE(a.w_dev && (a.x3_dev || ((a.attn_q_dev || a.pick) && a.epilogue == SMOLTTS_EPI_RESID)), SMOLTTS_E_INVALID, "gemm3: null operand");
   ST_REQUIRE(a.ssq_in_dev == nullptr || a.K % 64 == 0, SMOLTTS_E_INVALID, "gemm3: normed input needs K %% 64 == 0");
   Gemm3Dev d;
   memset(&d, 0, sizeof(d));
@@ -923,6 +1059,7 @@ static int launch_gemm3_impl(const SmolttsGemm3Args& a, hipStream_t stream) {
   d.kv_bf16 = a.kv_format == SMOLTTS_KV_BF16;
   d.w_nt = a.w_stream != 0;
   d.v_x3 = a.epilogue == SMOLTTS_EPI_QKV_ROPE ? (char*)a.v_x3_dev : nullptr;
+  d.cand = a.epilogue == SMOLTTS_EPI_STORE ? a.cand_out_dev : nullptr;
 #ifdef SMOLTTS_DEBUG_HOOKS
   d.stamps = debug_stamp_buffer();
 #endif
@@ -932,9 +1069,18 @@ static int launch_gemm3_impl(const SmolttsGemm3Args& a, hipStream_t stream) {
       ST_REQUIRE(!(a.emit_a_dev || a.emit_b_dev || a.ssq_out_dev) || a.N % 64 == 0, SMOLTTS_E_INVALID, "gemm3: emission needs N %% 64 == 0");
       return launch3_epi<SMOLTTS_EPI_STORE>(d, stream);
     case SMOLTTS_EPI_RESID:
-      ST_REQUIRE(a.out_dev && a.resid_dev && a.ldo % 4 == 0, SMOLTTS_E_INVALID, "gemm3: RESID needs out/resid/ldo");
+      ST_REQUIRE(a.out_dev && (a.resid_dev || a.pick) && a.ldo % 4 == 0, SMOLTTS_E_INVALID, "gemm3: RESID needs out/resid/ldo");
       ST_REQUIRE(!(a.emit_a_dev || a.emit_b_dev || a.ssq_out_dev) || a.N % 64 == 0, SMOLTTS_E_INVALID, "gemm3: emission needs N %% 64 == 0");
-      if (a.attn_q_dev) {  // the activation operand is the depth-step attention of these rows, worked out inside the launch
+      if (a.pick) {  // ... with the previous step's code picked in front of it
+        const SmolttsPickArgs& k = *a.pick;
+        ST_REQUIRE(k.cand_dev && k.cand_tiles > 0 && k.qkv_table_dev && k.rope_dev && k.emb_dev && k.ids_dev && a.attn_pos >= 1 &&
+                       (!k.margin_at_dev || k.frames_dev) && a.M > 0,
+                   SMOLTTS_E_INVALID, "gemm3: pick arguments incomplete (or attn_pos < 1: step 0 has no pick in front of it)");
+        d.pk_cand = k.cand_dev; d.pk_tiles = k.cand_tiles; d.pk_table = k.qkv_table_dev; d.pk_rope = k.rope_dev;
+        d.pk_emb = (const uint16_t*)k.emb_dev; d.pk_off = k.emb_row_offset; d.pk_ids = k.ids_dev; d.pk_ids_stride = k.ids_stride;
+        d.pk_margin = k.margin_dev; d.pk_mask = k.margin_mask_dev; d.pk_margin_at = k.margin_at_dev; d.pk_frames = k.frames_dev; d.pk_step = k.step;
+      }
+      if (a.attn_q_dev || a.pick) {  // the activation operand is the depth-step attention of these rows, worked out inside the launch
         ST_REQUIRE(smoltts_gemm3_attn_fusable(a.n_q_heads, a.n_kv_heads, a.cache_len) && a.K == a.n_q_heads * 64 && a.k_cache_dev && a.v_cache_dev &&
                        a.kv_format == SMOLTTS_KV_F32 && a.attn_pos >= 0 && a.attn_pos < a.cache_len && !a.ssq_in_dev,
                    SMOLTTS_E_INVALID, "gemm3: attention prologue needs <= 12 query heads in groups of <= 4, <= 8 cache entries (fp32), "

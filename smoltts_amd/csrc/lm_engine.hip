@@ -97,6 +97,8 @@ struct SmolttsSession {
   bool split_attn;             // slow attention of few rows over two workgroups per (row, kv head) (SMOLTTS_OPT_SPLIT_ATTN)
   int stream_w;                // which weights of a decode frame are loaded with the non-temporal hint (SMOLTTS_OPT_STREAM_W, bit mask)
   bool fuse_depth_attn;        // depth attention worked out inside the wo launch (SMOLTTS_OPT_FUSE_DEPTH_ATTN)
+  bool fuse_pick;              // greedy depth codes picked inside the next step's layer-0 attention + wo launch (SMOLTTS_OPT_FUSE_PICK)
+  float* cand;                 // [B][codebook_size / 16][4]: the depth head GEMM's tile candidates for that pick
 };
 
 namespace {
@@ -141,6 +143,7 @@ void carve(SmolttsSession* s, char* base, size_t* total) {
   s->sd_ssq = cv.take<float>(R16 * (c.dim / 16));
   s->logits = cv.take<float>(B * (size_t)imax(c.vocab_size, c.codebook_size));
   s->logits_slow = cv.take<float>(B * (size_t)c.vocab_size);
+  s->cand = cv.take<float>(B * (size_t)((c.codebook_size + 15) / 16) * 4);
   const size_t kv = (size_t)c.n_layer * B * c.n_kv_head * s->max_seq * 64 * (s->kv_format == SMOLTTS_KV_BF16 ? 2 : 4);
   s->kc = cv.take<char>(kv);
   s->vc = cv.take<char>(kv);
@@ -321,7 +324,10 @@ int launch_gemm3_m(const SmolttsSession* s, const SmolttsGemm3Args& a, hipStream
 int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, int n_head, int n_kv, int inter, float* x,
               float* q, int M, const int* row_pos, const int* row_slot, const float* rope, void* kc, void* vc,
               int cache_len, const char* in_x3, const EmitArgs& next, hipStream_t st, bool first_pos = false,
-              int kv_format = SMOLTTS_KV_F32, int iota_pos = -1, bool qkv_done = false, int w_stream = 0) {
+              int kv_format = SMOLTTS_KV_F32, int iota_pos = -1, bool qkv_done = false, int w_stream = 0,
+              const SmolttsPickArgs* pick = nullptr) {
+  // pick: the rows' codes of the previous depth step have not been picked yet -- this block's attention + wo launch does it
+  // (q | k | v out of the table, residual = the picked embedding row: SmolttsPickArgs); implies qkv_done and the fused attention
   // w_stream: 1 = every matrix of the block, or a mask of SMOLTTS_STREAM_W_DEPTH_* bits (which of a depth block's matrices)
   // qkv_done: q and the cache rows of this block are in place already (gathered from the engine's fast_qkv table by the
   // kernel that picked the row's code): no wqkv launch
@@ -357,7 +363,9 @@ int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, i
     if (fused_attn) {
       a.attn_q_dev = q; a.attn_pos = iota_pos; a.k_cache_dev = (float*)kc; a.v_cache_dev = (float*)vc;
       a.n_q_heads = n_head; a.n_kv_heads = n_kv; a.cache_len = cache_len; a.kv_format = SMOLTTS_KV_F32;
+      a.pick = pick;
     }
+    ST_REQUIRE(pick == nullptr || fused_attn, SMOLTTS_E_STATE, "run_block: a pick needs the fused depth attention");
     ST_TRY(launch_gemm3(a, st));
   }
   {  // h = silu(w1 n) * (w3 n), n = RMSNorm(x); written as w2's operand
@@ -459,6 +467,12 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
   }
   const size_t fl_stride = (size_t)B * c.fast_n_kv_head * c.n_fast * 64;
   const bool table = e->fast_qkv != nullptr && s->use_qkv_table;
+  // greedy depth codes are picked by the launch that consumes them (the next step's layer-0 attention + wo: SmolttsPickArgs)
+  const bool pick_fused = s->fuse_pick && table && s->fuse_depth_attn && s->fast_temp <= 0.f && B < 256 && c.codebook_size % 16 == 0 &&
+                          c.fast_dim == c.fast_n_head * 64 && smoltts_gemm3_attn_fusable(c.fast_n_head, c.fast_n_kv_head, c.n_fast);
+  SmolttsPickArgs pk;
+  memset(&pk, 0, sizeof(pk));
+  bool pk_pending = false;  // step i - 1's code is still candidates in s->cand
   for (int i = 0; i < c.n_fast; ++i) {
     for (int l = 0; l < c.n_fast_layer; ++l) {
       const EmitArgs next{s->x3n,
@@ -468,7 +482,9 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
                        s->fastpos + (size_t)i * B, s->iota, (const float*)(A + e->w.fast_rope), s->fkc + l * fl_stride,
                        s->fvc + l * fl_stride, c.n_fast, (i == 0 && l == 0) ? first_x3 : s->x3n, next, st, /*first_pos=*/i == 0,
                        SMOLTTS_KV_F32, /*iota_pos=*/i, /*qkv_done=*/table && i > 0 && l == 0,
-                       /*w_stream=*/s->stream_w & (SMOLTTS_STREAM_W_DEPTH_QKVO | SMOLTTS_STREAM_W_DEPTH_W13 | SMOLTTS_STREAM_W_DEPTH_W2)));
+                       /*w_stream=*/s->stream_w & (SMOLTTS_STREAM_W_DEPTH_QKVO | SMOLTTS_STREAM_W_DEPTH_W13 | SMOLTTS_STREAM_W_DEPTH_W2),
+                       (pk_pending && l == 0) ? &pk : nullptr));
+      if (l == 0) pk_pending = false;
     }
     {  // fast_norm + depthwise head slice i  (lm/rq_transformer.py:209-217)
       const size_t wrow = (size_t)i * e->w.fast_head_step_stride;  // rows; a row tile is 16 rows
@@ -476,6 +492,7 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
       SmolttsGemm3Args a = base3(c.weight_format, A + e->w.fast_head + wbytes, s->x3n, B, c.codebook_size, c.fast_dim, SMOLTTS_EPI_STORE);
       a.ssq_in_dev = s->ssq; a.eps = c.norm_eps; a.out_dev = s->logits; a.ldo = c.codebook_size;
       a.w_stream = (s->stream_w & SMOLTTS_STREAM_W_DEPTH_HEAD) != 0;  // each head slice is read once per frame
+      if (pick_fused && i + 1 < c.n_fast) a.cand_out_dev = s->cand;
       ST_TRY(launch_gemm3_m(s, a, st));
     }
     const SampleArgs fast_sa{s->fast_temp, s->fast_temp > 0.f ? s->min_p : 0.f, s->seed, 1 + i, 0, s->frames, s->salt, s->margin_at};
@@ -487,6 +504,15 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
     }
     const int off = c.depthwise_wte ? (c.duplicate_code_0 ? i : i + 1) * c.codebook_size : 0;  // generate.py:136-140
     float* xnext = c.has_fast_project_in ? s->xf : s->xt;
+    if (pick_fused) {  // no launch here: layer 0 of step i + 1 picks (the residual row it starts from is the embedding row itself)
+      pk.cand_dev = s->cand; pk.cand_tiles = c.codebook_size / 16; pk.qkv_table_dev = e->fast_qkv;
+      pk.rope_dev = (const float*)(A + e->w.fast_rope); pk.emb_dev = A + e->w.fast_emb; pk.emb_row_offset = off;
+      pk.ids_dev = s->new_col + 1 + i; pk.ids_stride = H; pk.margin_dev = s->margin; pk.margin_mask_dev = s->mask;
+      pk.margin_at_dev = s->margin_at; pk.frames_dev = s->frames; pk.step = 1 + i;
+      pk_pending = true;
+      xf = xnext;
+      continue;
+    }
     // the next step's layer-0 q | k | v come out of the engine's table (position i + 1) where it has been built: the row then
     // needs no X3 operand of its own, only the fp32 residual
     QkvGather qg;
@@ -770,6 +796,7 @@ int smoltts_session_create_kv(SmolttsEngine* e, void* slab_dev, size_t slab_byte
   s->split_attn = true;
   s->stream_w = SMOLTTS_STREAM_W_DEFAULT;
   s->fuse_depth_attn = true;
+  s->fuse_pick = true;
   s->kv_format = kv_format;
   size_t total = 0;
   carve(s, (char*)slab_dev, &total);
@@ -1053,6 +1080,7 @@ int smoltts_session_set_option(SmolttsSession* s, int32_t option, int32_t value)
     case SMOLTTS_OPT_SPLIT_ATTN: s->split_attn = value != 0; break;
     case SMOLTTS_OPT_STREAM_W: s->stream_w = value; break;
     case SMOLTTS_OPT_FUSE_DEPTH_ATTN: s->fuse_depth_attn = value != 0; break;
+    case SMOLTTS_OPT_FUSE_PICK: s->fuse_pick = value != 0; break;
     default:
       set_error("session_set_option: unknown option %d", option);
       return SMOLTTS_E_INVALID;

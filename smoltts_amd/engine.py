@@ -295,7 +295,7 @@ def _fill_block(dst: BlockWeights, src: Dict[str, int]) -> None:
         setattr(dst, k, v)
 
 
-OPT_QKV_TABLE, OPT_COMMIT_PICKS, OPT_SPLIT_ATTN, OPT_STREAM_W, OPT_FUSE_DEPTH_ATTN = 1, 2, 3, 4, 5  # include/smoltts_hip.h SMOLTTS_OPT_*
+OPT_QKV_TABLE, OPT_COMMIT_PICKS, OPT_SPLIT_ATTN, OPT_STREAM_W, OPT_FUSE_DEPTH_ATTN, OPT_FUSE_PICK = 1, 2, 3, 4, 5, 6  # include/smoltts_hip.h SMOLTTS_OPT_*
 
 
 class LMEngine:
@@ -408,6 +408,8 @@ class LMSession:
             self.use_split_attention(False)
         if os.environ.get("SMOLTTS_FUSE_DEPTH_ATTN") == "0":
             self.use_fused_depth_attention(False)
+        if os.environ.get("SMOLTTS_FUSE_PICK") == "0":
+            self.use_fused_pick(False)
         if os.environ.get("SMOLTTS_STREAM_W") is not None:  # mask of SMOLTTS_STREAM_W_* bits
             check(self.lib.smoltts_session_set_option(self.handle, OPT_STREAM_W, int(os.environ["SMOLTTS_STREAM_W"])), "smoltts_session_set_option")
 
@@ -537,6 +539,10 @@ class LMSession:
     def use_fused_depth_attention(self, on: bool) -> None:
         """Depth steps 1..: attention over the <= 8-entry cache inside the wo launch (default) or as a launch of its own."""
         check(self.lib.smoltts_session_set_option(self.handle, OPT_FUSE_DEPTH_ATTN, 1 if on else 0), "smoltts_session_set_option")
+
+    def use_fused_pick(self, on: bool) -> None:
+        """Greedy depth codes picked inside the next step's layer-0 attention + wo launch (default) or by a launch of their own."""
+        check(self.lib.smoltts_session_set_option(self.handle, OPT_FUSE_PICK, 1 if on else 0), "smoltts_session_set_option")
 
     def use_commit_picks(self, on: bool) -> None:
         """The frame's slow token and last depth code picked inside the commit kernel (default) or in launches of their own."""

@@ -171,3 +171,61 @@ def test_fused_and_unfused_frames_emit_the_same_ids(name, fmt):
         if key[1] == base_table:
             assert np.array_equal(got[1], base[1])  # fused == unfused bit for bit: the same smallest top-2 gaps
     eng.close()
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 2048, 768), (5, 2048, 576), (33, 64, 64), (130, 2048, 384)])
+def test_head_gemm_leaves_the_tile_candidates_of_a_greedy_pick(E, ops, M, N, K):
+    """EPI_STORE with cand_out_dev: per (row, 16-column tile) the largest value, the FIRST column holding it and the runner-up --
+    merged over the tiles they give torch.argmax (first maximal index) and the top-2 gap of the row."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g)
+    w = bf16r(torch.randn(N, K, generator=g) * 0.05)
+    w[7] = w[3]            # equal columns: the first one must win
+    w[N - 1] = w[N - 17]   # ... also across tiles
+    gamma = torch.ones(K)
+    x3, _, ssq = ops.x3_pack(x.cuda(), gamma.cuda())
+    tiles = (N + 15) // 16
+    cand = torch.full((M, tiles, 4), float("nan")).cuda()
+    out = ops.linear3(x3, ops.pack_weight(w), M, N, K, ssq_in=ssq, cand_out=cand)
+    lg = out.cpu()
+    c = cand.cpu()
+    v1, i1, v2 = c[..., 0], c[..., 1].contiguous().view(torch.int32), c[..., 2]
+    for r in range(M):
+        row = lg[r]
+        for t in range(tiles):
+            seg = row[t * 16:(t + 1) * 16]
+            assert float(v1[r, t]) == float(seg.max()) and int(i1[r, t]) == t * 16 + int(seg.argmax())
+            assert float(v2[r, t]) == float(seg.topk(2).values[1])
+        best = int(torch.argmax(v1[r]))  # torch.argmax: first maximal tile
+        assert int(i1[r, best]) == int(row.argmax())
+
+
+@pytest.mark.parametrize("name,fmt,B", [("tiny", "bf16", 6), ("tiny_nodup", "bf16", 6), ("smoltts_byte_70m", "bf16", 6), ("smoltts_byte_150m", "bf16", 3),
+                                        ("smoltts_byte_150m", "bf16", 33), ("tiny", "fp8", 6)])
+def test_pick_inside_the_attention_launch_gives_the_same_ids_and_gap_records(name, fmt, B):
+    """SMOLTTS_OPT_FUSE_PICK: the greedy depth codes picked by the next step's layer-0 attention + wo launch (SmolttsPickArgs) against
+    the picking kernel's launches: same ids, same smallest top-2 gaps, same (frame, step) records -- bit for bit."""
+    from smoltts_amd.config import TokenConfig
+    from smoltts_amd.engine import LMEngine, LMSession
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+    from smoltts_amd.tokenizer import load_tokenizer
+
+    cfg = named_config(name)
+    tok = load_tokenizer()
+    tc = TokenConfig.from_tokenizer(tok, cfg)
+    eng = LMEngine(cfg, synthetic_lm_state(cfg, seed=17), tc, weight_format=fmt)
+    prompts = (_prompts(cfg, tok, tc, TEXTS) * 6)[:B]
+    F = 10
+    out = {}
+    for pick in (True, False):
+        s = LMSession(eng, max_batch=B, max_seq=256, max_rows=2048, max_frames=F)
+        s.use_fused_pick(pick)
+        s.prefill(prompts, stop_on_eos=False)
+        s.decode(F - 1)
+        codes, n, _, margin = s.fetch()
+        assert (n == F).all()
+        out[pick] = (codes[:, :F].copy(), margin.copy(), s.margin_at.cpu().numpy().copy())
+        s.close()
+    assert np.array_equal(out[True][0], out[False][0]), "ids differ between the pick inside the launch and the picking kernel"
+    assert np.array_equal(out[True][1], out[False][1]) and np.array_equal(out[True][2], out[False][2])
+    eng.close()
