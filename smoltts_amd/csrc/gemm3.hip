@@ -778,30 +778,19 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(Gemm3Dev p) {
     // PICK: the previous step's code of both rows, by every attention wave (the candidates are 2 KB per row, and the finishing
     // waves need both rows' embedding rows): id -> row of the embedding / q | k | v tables
     long erow0 = 0, erow1 = 0;
+    Top2 t0{0.f, 0, 0.f}, t1 = t0;
+#if SMOLTTS_DBG_AWO_ORDER
+    if (PICK) __syncthreads();  // (the GEMM waves' go: with a pick in front, this wave's own loads come too late to wait for)
+#endif
     if (PICK) {
       const int n_cols = p.pk_tiles * 16;
-      Top2 t0 = awo_pick_row(p.pk_cand + (size_t)row0 * p.pk_tiles * 4, p.pk_tiles, lane), t1 = t0;
+      t0 = awo_pick_row(p.pk_cand + (size_t)row0 * p.pk_tiles * 4, p.pk_tiles, lane);
+      t1 = t0;
       if (row0 + 1 < p.M) t1 = awo_pick_row(p.pk_cand + (size_t)(row0 + 1) * p.pk_tiles * 4, p.pk_tiles, lane);
       if (t0.i1 < 0 || t0.i1 >= n_cols) t0.i1 = 0;  // all-NaN row: stay inside the tables (argmax_row does the same)
       if (t1.i1 < 0 || t1.i1 >= n_cols) t1.i1 = 0;
       erow0 = (long)t0.i1 + p.pk_off;
       erow1 = (long)t1.i1 + p.pk_off;
-      if (blockIdx.x == 0 && wave == 0 && lane == 0) {  // the records of the picking kernel (argmax_row), once per row
-#pragma unroll
-        for (int rl = 0; rl < R; ++rl) {
-          const int row = row0 + rl;
-          if (row >= p.M) break;
-          const Top2 t = rl ? t1 : t0;
-          p.pk_ids[(long)row * p.pk_ids_stride] = t.i1;
-          if (p.pk_margin && (p.pk_mask == nullptr || p.pk_mask[row])) {
-            const float gap = t.v1 - t.v2;
-            if (gap < p.pk_margin[row]) {
-              p.pk_margin[row] = gap;
-              if (p.pk_margin_at) p.pk_margin_at[row] = p.pk_frames[row] * 64 + p.pk_step;
-            }
-          }
-        }
-      }
     }
     AwoUnit<G, TWO> un;
     if (wave < n_units) awo_load<G, TWO, PICK>(un, p, wave, kv_pairs, row0, lane, wave / kv_pairs ? erow1 : erow0, blockIdx.x == 0);
@@ -831,7 +820,7 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(Gemm3Dev p) {
     }
     STAMP3(5);
 #if SMOLTTS_DBG_AWO_ORDER
-    __syncthreads();  // (lets the GEMM waves start their weight stream: see there)
+    if (!PICK) __syncthreads();  // (lets the GEMM waves start their weight stream: see there)
 #endif
     if (wave < n_units) awo_compute(un, frag, lane);
     for (int unit = wave + NA; unit < n_units; unit += NA) {  // (more than 2 x NA / R kv heads: no shipped config)
@@ -842,6 +831,24 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(Gemm3Dev p) {
     __syncthreads();  // the fragments are in LDS
     __syncthreads();  // the GEMM waves' partial tiles are in LDS
     STAMP3(3);
+    if (PICK && blockIdx.x == 0 && wave == NA - 1 && lane == 0) {
+      // the records of the picking kernel (argmax_row), once per row, by a wave that has nothing left to do (NA - 1 >= T: not a
+      // finishing wave): its dependent loads (mask, smallest gap so far, frame number) are on nobody's critical path here
+#pragma unroll
+      for (int rl = 0; rl < R; ++rl) {
+        const int row = row0 + rl;
+        if (row >= p.M) break;
+        const Top2 t = rl ? t1 : t0;
+        p.pk_ids[(long)row * p.pk_ids_stride] = t.i1;
+        if (p.pk_margin && (p.pk_mask == nullptr || p.pk_mask[row])) {
+          const float gap = t.v1 - t.v2;
+          if (gap < p.pk_margin[row]) {
+            p.pk_margin[row] = gap;
+            if (p.pk_margin_at) p.pk_margin_at[row] = p.pk_frames[row] * 64 + p.pk_step;
+          }
+        }
+      }
+    }
     if (!fin) return;
     float4 part[NB];  // (gemm3_kernel's reduction, term for term)
 #pragma unroll
