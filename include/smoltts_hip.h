@@ -497,7 +497,8 @@ typedef struct SmolttsGemm3Args {
   const float* attn_q_dev;     /* fp32 [M][n_q_heads*64] (RoPE applied: the q rows an EPI_QKV_ROPE launch wrote) */
   int32_t attn_pos;
   /* EPI_STORE (ABI 5): also leave, for every (row, 16-column tile) of the result, the tile's largest value, the first column that
-   * holds it (int32 bits) and the runner-up: float [M][ceil(N/16)][4] (4th unused) -- what a greedy pick needs of a row of logits */
+   * holds it (int32 bits) and the runner-up: float [M][ceil(N/16)][4] (4th unused) -- what a greedy pick needs of a row of logits
+   * (M < 256: the many-row kernel has no such epilogue) */
   float* cand_out_dev;
   /* the attention prologue with the PICK in front of it (ABI 5; NULL = off): the rows are depth step attn_pos of a frame whose
    * previous head GEMM left cand_out_dev; see SmolttsPickArgs.  attn_q_dev and resid_dev are then not read. */

@@ -1073,6 +1073,7 @@ static int launch_gemm3_impl(const SmolttsGemm3Args& a, hipStream_t stream) {
   switch (a.epilogue) {
     case SMOLTTS_EPI_STORE:
       ST_REQUIRE(a.out_dev && a.ldo % 4 == 0, SMOLTTS_E_INVALID, "gemm3: STORE needs out/ldo");
+      ST_REQUIRE(a.cand_out_dev == nullptr || a.M < 256, SMOLTTS_E_INVALID, "gemm3: cand_out_dev needs M < 256 (the many-row kernel leaves no candidates)");
       ST_REQUIRE(!(a.emit_a_dev || a.emit_b_dev || a.ssq_out_dev) || a.N % 64 == 0, SMOLTTS_E_INVALID, "gemm3: emission needs N %% 64 == 0");
       return launch3_epi<SMOLTTS_EPI_STORE>(d, stream);
     case SMOLTTS_EPI_RESID:
