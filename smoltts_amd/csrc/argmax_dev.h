@@ -137,6 +137,49 @@ __device__ __forceinline__ int argmax_row(const float* row, int n_cols, bool ld_
   return a.i1;  // the same value in every thread (merged from LDS)
 }
 
+// The picked id of one row from the head GEMM's tile candidates (SmolttsGemm3Args.cand_out_dev layout), by a whole wave: every lane returns it.
+// The merge across lanes stays on the VALU (DPP inside 16-lane rows, v_permlane16/32_swap across them): six dependent
+// ds_bpermute round trips per row -- what __shfl_xor compiles to -- were most of what the pick added to the launch.
+template <int CTRL>
+__device__ __forceinline__ Top2 top2_dpp(Top2 t) {
+  Top2 b;
+  b.v1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t.v1), CTRL, 0xF, 0xF, true));
+  b.i1 = __builtin_amdgcn_update_dpp(0, t.i1, CTRL, 0xF, 0xF, true);
+  b.v2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t.v2), CTRL, 0xF, 0xF, true));
+  return top2_merge(t, b);
+}
+template <bool ROWS32>
+__device__ __forceinline__ Top2 top2_swap(Top2 t, int lane) {  // partner = lane ^ 16 (ROWS32: lane ^ 32)
+  const unsigned a[3] = {__float_as_uint(t.v1), (unsigned)t.i1, __float_as_uint(t.v2)};
+  unsigned o[3];
+  const bool upper = (lane & (ROWS32 ? 32 : 16)) != 0;  // after swap(x, x): the lower lane's partner value is result 1, the upper's result 0
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (ROWS32) {
+      const auto r = __builtin_amdgcn_permlane32_swap(a[i], a[i], false, false);
+      o[i] = upper ? r[0] : r[1];
+    } else {
+      const auto r = __builtin_amdgcn_permlane16_swap(a[i], a[i], false, false);
+      o[i] = upper ? r[0] : r[1];
+    }
+  }
+  return top2_merge(t, Top2{__uint_as_float(o[0]), (int)o[1], __uint_as_float(o[2])});
+}
+__device__ __forceinline__ Top2 cand_pick_wave(const float* cand, int tiles, int lane) {
+  Top2 t{-INFINITY, 0x7fffffff, -INFINITY};
+  for (int j = lane; j < tiles; j += 64) {
+    const float4 c = *reinterpret_cast<const float4*>(cand + (size_t)j * 4);
+    t = top2_merge(t, Top2{c.x, __float_as_int(c.y), c.z});
+  }
+  t = top2_dpp<0xB1>(t);   // lane ^ 1
+  t = top2_dpp<0x4E>(t);   // lane ^ 2
+  t = top2_dpp<0x141>(t);  // the other quad of the half row
+  t = top2_dpp<0x140>(t);  // the other half row
+  t = top2_swap<false>(t, lane);
+  t = top2_swap<true>(t, lane);
+  return t;
+}
+
 // Projections of a depth-transformer input row that are known before the row is: row e of the fast embedding table always
 // enters layer 0 as RMSNorm(E[e]) -> wqkv, so q | k | v (before RoPE) are a table lookup [rows][nqkv] instead of a GEMM launch
 // (smoltts_engine_build_fast_qkv).  The kernel that picks the code gathers them, applies RoPE for the row's position and writes

@@ -644,49 +644,6 @@ __device__ __forceinline__ void awo_load(AwoUnit<G, TWO>& u, const Gemm3Dev& p, 
   }
 }
 
-// The picked id of one row from the head GEMM's tile candidates (Gemm3Dev.cand layout), by a whole wave: every lane returns it.
-// The merge across lanes stays on the VALU (DPP inside 16-lane rows, v_permlane16/32_swap across them): six dependent
-// ds_bpermute round trips per row -- what __shfl_xor compiles to -- were most of what the pick added to the launch.
-template <int CTRL>
-__device__ __forceinline__ Top2 top2_dpp(Top2 t) {
-  Top2 b;
-  b.v1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t.v1), CTRL, 0xF, 0xF, true));
-  b.i1 = __builtin_amdgcn_update_dpp(0, t.i1, CTRL, 0xF, 0xF, true);
-  b.v2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t.v2), CTRL, 0xF, 0xF, true));
-  return top2_merge(t, b);
-}
-template <bool ROWS32>
-__device__ __forceinline__ Top2 top2_swap(Top2 t, int lane) {  // partner = lane ^ 16 (ROWS32: lane ^ 32)
-  const unsigned a[3] = {__float_as_uint(t.v1), (unsigned)t.i1, __float_as_uint(t.v2)};
-  unsigned o[3];
-  const bool upper = (lane & (ROWS32 ? 32 : 16)) != 0;  // after swap(x, x): the lower lane's partner value is result 1, the upper's result 0
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    if (ROWS32) {
-      const auto r = __builtin_amdgcn_permlane32_swap(a[i], a[i], false, false);
-      o[i] = upper ? r[0] : r[1];
-    } else {
-      const auto r = __builtin_amdgcn_permlane16_swap(a[i], a[i], false, false);
-      o[i] = upper ? r[0] : r[1];
-    }
-  }
-  return top2_merge(t, Top2{__uint_as_float(o[0]), (int)o[1], __uint_as_float(o[2])});
-}
-__device__ __forceinline__ Top2 awo_pick_row(const float* cand, int tiles, int lane) {
-  Top2 t{-INFINITY, 0x7fffffff, -INFINITY};
-  for (int j = lane; j < tiles; j += 64) {
-    const float4 c = *reinterpret_cast<const float4*>(cand + (size_t)j * 4);
-    t = top2_merge(t, Top2{c.x, __float_as_int(c.y), c.z});
-  }
-  t = top2_dpp<0xB1>(t);   // lane ^ 1
-  t = top2_dpp<0x4E>(t);   // lane ^ 2
-  t = top2_dpp<0x141>(t);  // the other quad of the half row
-  t = top2_dpp<0x140>(t);  // the other half row
-  t = top2_swap<false>(t, lane);
-  t = top2_swap<true>(t, lane);
-  return t;
-}
-
 template <int G, bool TWO>
 __device__ __forceinline__ void awo_compute(const AwoUnit<G, TWO>& u, char* frag, int lane) {
   // No contraction of this function's products into later additions (written as plain `*` HERE: `__fmul_rn` is a header function
@@ -784,9 +741,9 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(Gemm3Dev p) {
 #endif
     if (PICK) {
       const int n_cols = p.pk_tiles * 16;
-      t0 = awo_pick_row(p.pk_cand + (size_t)row0 * p.pk_tiles * 4, p.pk_tiles, lane);
+      t0 = cand_pick_wave(p.pk_cand + (size_t)row0 * p.pk_tiles * 4, p.pk_tiles, lane);
       t1 = t0;
-      if (row0 + 1 < p.M) t1 = awo_pick_row(p.pk_cand + (size_t)(row0 + 1) * p.pk_tiles * 4, p.pk_tiles, lane);
+      if (row0 + 1 < p.M) t1 = cand_pick_wave(p.pk_cand + (size_t)(row0 + 1) * p.pk_tiles * 4, p.pk_tiles, lane);
       if (t0.i1 < 0 || t0.i1 >= n_cols) t0.i1 = 0;  // all-NaN row: stay inside the tables (argmax_row does the same)
       if (t1.i1 < 0 || t1.i1 >= n_cols) t1.i1 = 0;
       erow0 = (long)t0.i1 + p.pk_off;

@@ -99,6 +99,7 @@ struct SmolttsSession {
   bool fuse_depth_attn;        // depth attention worked out inside the wo launch (SMOLTTS_OPT_FUSE_DEPTH_ATTN)
   bool fuse_pick;              // greedy depth codes picked inside the next step's layer-0 attention + wo launch (SMOLTTS_OPT_FUSE_PICK)
   float* cand;                 // [B][codebook_size / 16][4]: the depth head GEMM's tile candidates for that pick
+  float* cand_slow;            // [B][vocab_size / 16][4]: the slow head GEMM's, for the commit kernel's greedy pick
 };
 
 namespace {
@@ -144,6 +145,7 @@ void carve(SmolttsSession* s, char* base, size_t* total) {
   s->logits = cv.take<float>(B * (size_t)imax(c.vocab_size, c.codebook_size));
   s->logits_slow = cv.take<float>(B * (size_t)c.vocab_size);
   s->cand = cv.take<float>(B * (size_t)((c.codebook_size + 15) / 16) * 4);
+  s->cand_slow = cv.take<float>(B * (size_t)((c.vocab_size + 15) / 16) * 4);
   const size_t kv = (size_t)c.n_layer * B * c.n_kv_head * s->max_seq * 64 * (s->kv_format == SMOLTTS_KV_BF16 ? 2 : 4);
   s->kc = cv.take<char>(kv);
   s->vc = cv.take<char>(kv);
@@ -252,6 +254,10 @@ struct CommitArgs {
   const float* slow_logits; int slow_cols; SampleArgs slow_sa;
   const float* last_logits; int last_cols; SampleArgs last_sa;
   float* margin;
+  // greedy picks from the head GEMMs' tile candidates (SmolttsGemm3Args.cand_out_dev) instead of the rows of logits: one wave
+  // each, side by side, 2.4 KB instead of 9.5 + 8 KB per slot to look at; null = from the logits (argmax_row: sampling)
+  const float* slow_cand; int slow_tiles;
+  const float* last_cand; int last_tiles;
   int* attn_ticket;  // the key-split attention's arrival tickets: back to zero at the end of every frame, so that no history (an
                      // interrupted launch, a caller's odd count) can invert a later launch's "who arrived last" decision
 };
@@ -264,8 +270,34 @@ __global__ __launch_bounds__(256) void commit_embed_kernel(CommitArgs a, EmbedTa
   if (b == 0 && a.attn_ticket)
     for (int i = tid; i < ATT_SPLIT_MAX_PAIRS; i += blockDim.x) a.attn_ticket[i] = 0;
   int id_slow = 0, id_last = 0;
-  if (a.slow_logits) id_slow = argmax_row(a.slow_logits + (long)b * a.slow_cols, a.slow_cols, (a.slow_cols & 3) == 0, b, a.margin, a.mask, a.slow_sa, s_pick[0]);
-  if (a.last_logits) id_last = argmax_row(a.last_logits + (long)b * a.last_cols, a.last_cols, (a.last_cols & 3) == 0, b, a.margin, a.mask, a.last_sa, s_pick[1]);
+  const bool c_slow = a.slow_logits && a.slow_cand, c_last = a.last_logits && a.last_cand;
+  if (c_slow || c_last) {  // (uniform) greedy picks from tile candidates: wave 0 the slow token, wave 1 the last depth code
+    __shared__ int s_id[2];
+    __shared__ float s_gap[2];
+    const int wave = tid >> 6, lane = tid & 63;
+    if ((wave == 0 && c_slow) || (wave == 1 && c_last)) {
+      const float* cand = wave == 0 ? a.slow_cand + (size_t)b * a.slow_tiles * 4 : a.last_cand + (size_t)b * a.last_tiles * 4;
+      Top2 t = cand_pick_wave(cand, wave == 0 ? a.slow_tiles : a.last_tiles, lane);
+      if (t.i1 < 0 || t.i1 >= (wave == 0 ? a.slow_cols : a.last_cols)) t.i1 = 0;  // all-NaN row: stay inside the tables
+      if (lane == 0) { s_id[wave] = t.i1; s_gap[wave] = t.v1 - t.v2; }
+    }
+    __syncthreads();
+    if (tid == 0 && a.margin && a.mask[b]) {  // argmax_row's gap records, in its order: the slow token's, then the last code's
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (!(k == 0 ? c_slow : c_last)) continue;
+        const SampleArgs& sa = k == 0 ? a.slow_sa : a.last_sa;
+        if (s_gap[k] < a.margin[b]) {
+          a.margin[b] = s_gap[k];
+          if (sa.margin_at) sa.margin_at[b] = (sa.frames ? sa.frames[b] : sa.frame_base + b) * 64 + sa.step;
+        }
+      }
+    }
+    if (c_slow) id_slow = s_id[0];
+    if (c_last) id_last = s_id[1];
+  }
+  if (a.slow_logits && !c_slow) id_slow = argmax_row(a.slow_logits + (long)b * a.slow_cols, a.slow_cols, (a.slow_cols & 3) == 0, b, a.margin, a.mask, a.slow_sa, s_pick[0]);
+  if (a.last_logits && !c_last) id_last = argmax_row(a.last_logits + (long)b * a.last_cols, a.last_cols, (a.last_cols & 3) == 0, b, a.margin, a.mask, a.last_sa, s_pick[1]);
   int f = 0;
   bool live = false;
   if (tid < 64) { f = a.frames[b]; live = a.do_commit && a.mask[b]; }
@@ -411,6 +443,10 @@ EmbedTables embed_tables(const SmolttsEngine* e) {
                      c.vocab_size, c.codebook_size * c.num_codebooks, c.n_fast};
 }
 
+// The commit kernel's greedy picks read the head GEMMs' tile candidates where run_tail has had them written (same conditions there)
+bool commit_cand_slow(const SmolttsSession* s) { return s->commit_picks && s->fuse_pick && s->temp <= 0.f && s->B < 256; }
+bool commit_cand_last(const SmolttsSession* s) { return s->commit_picks && s->fuse_pick && s->fast_temp <= 0.f && s->B < 256; }
+
 // commit (optional) + next-frame mask + embedding of every slot's current column (see commit_embed_kernel); `picks`: the
 // frame's slow token and last depth code are still logits (run_tail) and are picked here
 int launch_commit_embed(SmolttsSession* s, int do_commit, int advance_pos, hipStream_t st, bool picks = false) {
@@ -429,6 +465,8 @@ int launch_commit_embed(SmolttsSession* s, int do_commit, int advance_pos, hipSt
     a.slow_sa = SampleArgs{s->temp, s->min_p, s->seed, 0, 0, s->frames, s->salt, s->margin_at};
     a.last_logits = s->logits; a.last_cols = c.codebook_size;
     a.last_sa = SampleArgs{s->fast_temp, s->fast_temp > 0.f ? s->min_p : 0.f, s->seed, c.n_fast, 0, s->frames, s->salt, s->margin_at};
+    if (commit_cand_slow(s)) { a.slow_cand = s->cand_slow; a.slow_tiles = (c.vocab_size + 15) / 16; }
+    if (commit_cand_last(s)) { a.last_cand = s->cand; a.last_tiles = (c.codebook_size + 15) / 16; }
   }
   const EmitDev em{s->x3n, gamma_at(e, e->w.layers[0].attn_norm), nullptr, nullptr, s->ssq};
   hipLaunchKernelGGL(commit_embed_kernel, dim3(s->B), dim3(256), 0, st, a, embed_tables(e), s->xt, em);
@@ -446,6 +484,7 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
   {  // logits = RMSNorm(x) . E^T   (lm/rq_transformer.py:184-189); the token is picked by the commit kernel: nothing before it needs it
     SmolttsGemm3Args a = base3(c.weight_format, A + e->w.head, s->x3n, B, c.vocab_size, c.dim, SMOLTTS_EPI_STORE);
     a.ssq_in_dev = s->ssq; a.eps = c.norm_eps; a.out_dev = s->logits_slow; a.ldo = c.vocab_size; a.w_stream = (s->stream_w & SMOLTTS_STREAM_W_SLOW_HEAD) != 0;
+    if (commit_cand_slow(s)) a.cand_out_dev = s->cand_slow;
     ST_TRY(launch_gemm3_m(s, a, st));
   }
   const bool picks = s->commit_picks;
@@ -493,6 +532,7 @@ int run_tail(SmolttsSession* s, int advance_pos, hipStream_t st) {
       a.ssq_in_dev = s->ssq; a.eps = c.norm_eps; a.out_dev = s->logits; a.ldo = c.codebook_size;
       a.w_stream = (s->stream_w & SMOLTTS_STREAM_W_DEPTH_HEAD) != 0;  // each head slice is read once per frame
       if (pick_fused && i + 1 < c.n_fast) a.cand_out_dev = s->cand;
+      if (i + 1 == c.n_fast && commit_cand_last(s)) a.cand_out_dev = s->cand;  // (no pick is pending on the buffer at the last step)
       ST_TRY(launch_gemm3_m(s, a, st));
     }
     const SampleArgs fast_sa{s->fast_temp, s->fast_temp > 0.f ? s->min_p : 0.f, s->seed, 1 + i, 0, s->frames, s->salt, s->margin_at};
