@@ -217,7 +217,7 @@ int smoltts_lm_start_slots(SmolttsSession* s, const int32_t* grid_dev, const int
 int smoltts_lm_decode(SmolttsSession* s, int32_t n_frames, void* stream);
 
 /* Frames captured into one multi-frame graph of this session: n = 1 single-frame graphs only, 2..16 that many, 0 = follow
- * the decode calls (min(n_frames, 8) of the largest call so far -- the default).  Called after a prefill with n > 0 it also
+ * the decode calls (min(n_frames, 4) of the largest call so far -- the default).  Called after a prefill with n > 0 it also
  * captures the graphs now (on `stream`), so that the first decode call of a request does not pay the capture. */
 int smoltts_session_set_frames_per_graph(SmolttsSession* s, int32_t n, void* stream);
 /* Launch-structure options of a session (A/B runs, tests): the ids produced are the same either way; the captured graphs are dropped.

@@ -81,7 +81,7 @@ struct SmolttsSession {
   bool multi_ready;
   int flight_limit;            // SMOLTTS_MAX_FRAMES_IN_FLIGHT as read at creation (0 = unbounded)
   int multi_frames;            // frames per multi-frame graph (1 = single-frame graphs only): SMOLTTS_FRAMES_PER_GRAPH, else
-                               // smoltts_session_set_frames_per_graph, else min(n_frames, 8) of the largest decode call so far
+                               // smoltts_session_set_frames_per_graph, else min(n_frames, 4) of the largest decode call so far
   bool multi_fixed;            // set by the environment or the API: decode calls do not change it
   bool multi_env;              // set by SMOLTTS_FRAMES_PER_GRAPH: the API does not change it either
   bool prefilled;
@@ -863,7 +863,7 @@ int smoltts_session_create_kv(SmolttsEngine* e, void* slab_dev, size_t slab_byte
     for (int k = 0; k < 2; ++k)
       if (hipEventCreateWithFlags(&s->flight_ev[k], hipEventDisableTiming) != hipSuccess) s->flight_group = 0;
     const char* fpg = getenv("SMOLTTS_FRAMES_PER_GRAPH");  // frames captured into one graph where that many remain to be launched
-    s->multi_frames = fpg ? atoi(fpg) : 0;  // 0: follows the calls (smoltts_session_set_frames_per_graph, or min(n_frames, 8) of the largest call so far)
+    s->multi_frames = fpg ? atoi(fpg) : 0;  // 0: follows the calls (smoltts_session_set_frames_per_graph, or min(n_frames, 4) of the largest call so far)
     if (s->multi_frames < 0 || s->multi_frames > 16) s->multi_frames = 1;
     s->multi_fixed = s->multi_env = fpg != nullptr;
     s->flight_limit = limit;
@@ -1058,7 +1058,9 @@ int smoltts_lm_decode(SmolttsSession* s, int32_t n_frames, void* stream) {
   // Frames are launched `multi_frames` at a time where that many remain: every graph launch costs the GPU a gap between the
   // last node of one graph and the first of the next (measured: the frame rate of a 32-frame chunk rises by the gaps saved).
   if (!s->multi_fixed && n_frames >= 2) {  // follows the calls: a later, longer call (a tick after a 2-frame warm-up) re-captures
-    const int want = n_frames < 8 ? n_frames : 8;
+    // (4 since round 4: with 181 launches per frame graphs of 1 / 2 / 4 / 8 / 16 frames give 27.5 / 27.58 / 27.61 / 27.47 / 27.25k
+    // frames/s in the bench, profiles/r04_ab_frames_per_graph.txt; round 3's 216-launch frame was best at 8)
+    const int want = n_frames < 4 ? n_frames : 4;
     if (want > s->multi_frames) {
       s->multi_frames = want;
       if (s->multi_ready) { (void)hipGraphExecDestroy(s->multi_exec); s->multi_ready = false; }
