@@ -91,6 +91,7 @@ def parse_args(argv=None):
     ap.add_argument("--cu-pattern", default="low", choices=["low", "xcd"], help="which mask bits: the N lowest, or N/32 whole XCDs (bit i -> XCD i mod 8)")
     ap.add_argument("--lm-complement", action="store_true", help="restrict the frame-graph stream to the CUs the Mimi stream does not use")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"], help="weight format of the DualAR Linears (fp8 = e4m3 storage + row scales, dequantised to bf16 in registers: the MFMA operands stay bf16; BASELINE config 5; the model is then the dequantised one)")
+    ap.add_argument("--fp8-prefill", action="store_true", help="with --weights fp8: prompt prefills of >= 256 rows on the fp8 x fp8 MFMA (SMOLTTS_OPT_FP8_PREFILL: BASELINE configs[4]'s 'fp8 MFMA prefill'); the prompt KV rows are then approximate, ids are not comparable with the oracle: the oracle legs are skipped and the line says so")
     ap.add_argument("--streams", type=int, default=1, help="independent decode streams per GPU (slots are split evenly)")
     ap.add_argument("--kv", default="fp32", choices=["fp32", "bf16"], help="KV-cache storage of the slow transformer (bf16: K/V rounded once when written; the oracle rounds identically)")
     ap.add_argument("--rehearse-launcher", action="store_true", help="no GPU, no compute: start the ranks, run the distributed plumbing of the bench (rendezvous, ranks_seen all-reduce, weight broadcast, sharding, barriers, timing reductions) over gloo and print the line")
@@ -763,7 +764,8 @@ def run_rank(args) -> None:
         wdesc = ("fp8-e4m3 weights (storage format, row-scaled; dequantised to bf16 in registers, so the MFMA operands are bf16 -- no fp8 MFMA)"
                  if args.weights == "fp8" else "bf16 weights")
         out = {
-            "metric": "Mimi frames/sec (=12.5 x RTF), greedy DualAR decode + Mimi decode to PCM" + (" [DIAGNOSTIC: Mimi skipped]" if args.no_mimi else ""),
+            "metric": "Mimi frames/sec (=12.5 x RTF), greedy DualAR decode + Mimi decode to PCM" + (" [DIAGNOSTIC: Mimi skipped]" if args.no_mimi else "")
+                      + (" [fp8 MFMA prefill: prompt KV rows approximate, ids NOT comparable with the reference greedy decode]" if args.fp8_prefill else ""),
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "ranks_seen": seen, "steps": K, "warmup": W,
             "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": f"{wdesc}, fp32 activations/accumulate, {args.kv} KV cache (LM); fp32 (Mimi)",
@@ -791,6 +793,11 @@ def run_rank(args) -> None:
 
 def main():
     args = parse_args()
+    if args.fp8_prefill:
+        if args.weights != "fp8":
+            raise SystemExit("--fp8-prefill needs --weights fp8")
+        os.environ["SMOLTTS_FP8_PREFILL"] = "1"  # every LMSession of this process (children inherit it)
+        args.cpu_frames = 0  # no id parity with the oracle in this mode
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # not under a launcher: become one (before any GPU call)

@@ -234,6 +234,9 @@ int smoltts_session_set_frames_per_graph(SmolttsSession* s, int32_t n, void* str
 #define SMOLTTS_OPT_COMMIT_PICKS 2
 #define SMOLTTS_OPT_SPLIT_ATTN 3
 #define SMOLTTS_OPT_FUSE_DEPTH_ATTN 5
+#define SMOLTTS_OPT_FP8_PREFILL 7  /* (ABI 5; default 0) engines with fp8 weights: prompt prefills of >= 256 rows run their GEMMs with fp8
+                                      activations on the fp8 MFMA (SmolttsGemm3Args.fp8_activations): faster first chunk, prompt KV rows
+                                      approximate -- ids are then no longer guaranteed to equal the reference greedy decode */
 #define SMOLTTS_OPT_FUSE_PICK 6  /* (ABI 5) greedy depth codes picked inside the next step's layer-0 attention + wo launch (SmolttsPickArgs)
                                     instead of by a launch of their own (default 1; needs the fast_qkv table, the fused depth
                                     attention and greedy depth tokens); same ids, same gap records */
@@ -266,6 +269,9 @@ int smoltts_session_set_sampling(SmolttsSession* s, float temp, float fast_temp,
  *   margin     float [max_batch]   smallest top-1/top-2 logit gap seen by the slot's argmaxes */
 int smoltts_session_outputs(SmolttsSession* s, int32_t** codes_dev, int32_t** n_frames_dev,
                             int32_t** done_dev, float** margin_dev);
+/* Diagnostics: the slow transformer's KV cache of the session -- k / v [n_layer][max_batch][n_kv_head][max_seq][64] in the session's
+ * kv format (fp32 or bf16), `layer_bytes` apart per layer.  Read-only use (tests compare cache rows between launch structures). */
+int smoltts_session_kv_cache(SmolttsSession* s, void** k_dev, void** v_dev, uint64_t* layer_bytes);
 /* int32 [max_batch]: where each slot's smallest gap occurred, frame * 64 + step (step 0 = slow id, i = depth code i-1). */
 int smoltts_session_margin_at(SmolttsSession* s, int32_t** margin_at_dev);
 
@@ -503,6 +509,11 @@ typedef struct SmolttsGemm3Args {
   /* the attention prologue with the PICK in front of it (ABI 5; NULL = off): the rows are depth step attn_pos of a frame whose
    * previous head GEMM left cand_out_dev; see SmolttsPickArgs.  attn_q_dev and resid_dev are then not read. */
   const struct SmolttsPickArgs* pick;
+  /* SMOLTTS_W_FP8 weights, M >= 256 (prompt rows) only (ABI 5): != 0 runs the GEMM on the fp8 matrix-core instruction
+   * (v_mfma_f32_16x16x32_fp8_fp8) -- the weight tiles as they are, the activation operand's leading bf16 piece rounded to e4m3
+   * -- instead of three exact bf16 MFMAs per chunk: BASELINE configs[4]'s "fp8 MFMA prefill".  The result then carries the
+   * activations' fp8 rounding (~2^-4 relative per element, ~1e-3 of the output scale): NOT the parity path. */
+  int32_t fp8_activations;
 } SmolttsGemm3Args;
 
 /* Greedy pick of the previous depth step's code inside the launch that consumes it (depth layer 0 of the next step, whose q | k | v

@@ -38,6 +38,7 @@ struct Gemm3Dev {
   const char* x3;
   int M, N, K;
   int w_nt;       // weight loads carry the non-temporal hint (SmolttsGemm3Args.w_stream)
+  int f8_act;     // many-row calls with fp8 weights: fp8 x fp8 MFMA on the activation's hi piece rounded to e4m3 (fp8_activations)
   int half_rows;  // MT == 1 only: a workgroup owns 8 of the tile's 16 rows (twice the workgroups, half the X3 bytes each)
   const float* ssq_in;
   float eps;
@@ -376,67 +377,12 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
 // rows x 16*NTW*4 columns.  The X3 blocks of a 32-k chunk (4 row tiles x 3 pieces = 12 KiB, already in
 // B-fragment order) are copied into LDS once per chunk and shared by the 4 waves, each of which holds
 // NTW column tiles and accumulates the whole K itself: no split-K, no cross-wave reduction, the
-// activation operand leaves L2 once per 256 output columns instead of once per 16.
+// activation operand leaves L2 once per 256 output columns instead of once per 16.  (Kernel below its epilogue.)
+
+// Epilogue of the many-row kernels, straight from the accumulators (inputs loaded here: amortised over the long K loop).
 template <int NTW, int EPI, bool W8>
-__global__ __launch_bounds__(256) void gemm3_rows_kernel(Gemm3Dev p) {
-  constexpr int WTILE = W8 ? 512 : 1024, WLANE = W8 ? 8 : 16;
-  __shared__ uint4 xs[12 * 64];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int r = lane & 15, q = lane >> 4;
-  const int nchunks = p.K >> 5;
-  const int mtile0 = blockIdx.y * 4;
-  const int tile0 = (blockIdx.x * 4 + wave) * NTW;
+__device__ __forceinline__ void rows_epilogue(const Gemm3Dev& p, f32x4 (&acc)[NTW][4], int mtile0, int tile0, int r, int q) {
   constexpr bool kResid = EPI == SMOLTTS_EPI_RESID;
-
-  const char* sp[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int idx = tid + 256 * i, blk = idx >> 6, ln = idx & 63;
-    const int mt = blk / 3, pc = blk - mt * 3;
-    sp[i] = ((mtile0 + mt) * 16 < p.M) ? p.x3 + (size_t)(mtile0 + mt) * nchunks * 3072 + pc * 1024 + ln * 16 : nullptr;
-  }
-  const char* wb[NTW];
-  bool wv[NTW];
-#pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    wv[t] = (tile0 + t) * 16 < p.N;
-    wb[t] = p.w + (size_t)(tile0 + t) * nchunks * WTILE + lane * WLANE;
-  }
-  f32x4 acc[NTW][4];
-#pragma unroll
-  for (int t = 0; t < NTW; ++t)
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  uint4 stage[3], wnext[NTW];
-  auto fetch = [&](int c) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) stage[i] = sp[i] ? *reinterpret_cast<const uint4*>(sp[i] + (size_t)c * 3072) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) wnext[t] = wv[t] ? load_wfrag<W8>(wb[t] + (size_t)c * WTILE) : make_uint4(0, 0, 0, 0);
-  };
-  fetch(0);
-  for (int c = 0; c < nchunks; ++c) {
-    __syncthreads();  // previous chunk fully consumed
-#pragma unroll
-    for (int i = 0; i < 3; ++i) xs[tid + 256 * i] = stage[i];
-    bf16x8_t a[NTW];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) a[t] = wfrag_bf16<W8>(wnext[t]);
-    __syncthreads();
-    if (c + 1 < nchunks) fetch(c + 1);  // next chunk's loads fly under this chunk's MFMAs
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc) {
-        const bf16x8_t b = __builtin_bit_cast(bf16x8_t, xs[(mt * 3 + pc) * 64 + lane]);
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b, acc[t][mt], 0, 0, 0);
-      }
-    }
-  }
-
-  // ---- epilogue straight from the accumulators (inputs loaded here: amortised over the long K loop)
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int m = (mtile0 + mt) * 16 + r;
@@ -515,6 +461,132 @@ __global__ __launch_bounds__(256) void gemm3_rows_kernel(Gemm3Dev p) {
       }
     }
   }
+}
+
+template <int NTW, int EPI, bool W8>
+__global__ __launch_bounds__(256) void gemm3_rows_kernel(Gemm3Dev p) {
+  constexpr int WTILE = W8 ? 512 : 1024, WLANE = W8 ? 8 : 16;
+  __shared__ uint4 xs[12 * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int nchunks = p.K >> 5;
+  const int mtile0 = blockIdx.y * 4;
+  const int tile0 = (blockIdx.x * 4 + wave) * NTW;
+
+  const char* sp[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int idx = tid + 256 * i, blk = idx >> 6, ln = idx & 63;
+    const int mt = blk / 3, pc = blk - mt * 3;
+    sp[i] = ((mtile0 + mt) * 16 < p.M) ? p.x3 + (size_t)(mtile0 + mt) * nchunks * 3072 + pc * 1024 + ln * 16 : nullptr;
+  }
+  const char* wb[NTW];
+  bool wv[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    wv[t] = (tile0 + t) * 16 < p.N;
+    wb[t] = p.w + (size_t)(tile0 + t) * nchunks * WTILE + lane * WLANE;
+  }
+  f32x4 acc[NTW][4];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  uint4 stage[3], wnext[NTW];
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) stage[i] = sp[i] ? *reinterpret_cast<const uint4*>(sp[i] + (size_t)c * 3072) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) wnext[t] = wv[t] ? load_wfrag<W8>(wb[t] + (size_t)c * WTILE) : make_uint4(0, 0, 0, 0);
+  };
+  fetch(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();  // previous chunk fully consumed
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xs[tid + 256 * i] = stage[i];
+    bf16x8_t a[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) a[t] = wfrag_bf16<W8>(wnext[t]);
+    __syncthreads();
+    if (c + 1 < nchunks) fetch(c + 1);  // next chunk's loads fly under this chunk's MFMAs
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+        const bf16x8_t b = __builtin_bit_cast(bf16x8_t, xs[(mt * 3 + pc) * 64 + lane]);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b, acc[t][mt], 0, 0, 0);
+      }
+    }
+  }
+
+  rows_epilogue<NTW, EPI, W8>(p, acc, mtile0, tile0, r, q);
+}
+
+// fp8 x fp8 MFMA variant of the many-row kernel (BASELINE configs[4]: "CDNA4 fp8 MFMA prefill"; SMOLTTS_OPT_FP8_PREFILL): the e4m3
+// weight tiles go to the matrix cores as they are (no conversion on the operand path) and the activation operand is the X3
+// operand's hi piece rounded to e4m3 while it is staged into LDS (v_cvt_scalef32_pk_fp8_bf16, scale 1: RMSNorm-ed activations are
+// O(1)) -- one v_mfma_f32_16x16x32_fp8_fp8 per chunk and tile pair where the exact path runs three bf16 ones, a third of the
+// activation bytes.  Products of two e4m3 values are exact in fp32 and the accumulation is fp32; what is lost is the activation's
+// precision (3 mantissa bits): the prompt's KV rows are then an approximation, so ids are NOT guaranteed to equal the reference
+// greedy decode -- an opt-in mode, never the default.  Same epilogue (it still publishes exact X3 operands of ITS result).
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 bf16x8_to_fp8x8(uint4 v) {
+  s16x2_t a = {0, 0}, b = {0, 0};
+  a = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(a, __builtin_bit_cast(bf16x2_t, v.x), 1.0f, false);
+  a = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(a, __builtin_bit_cast(bf16x2_t, v.y), 1.0f, true);
+  b = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(b, __builtin_bit_cast(bf16x2_t, v.z), 1.0f, false);
+  b = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(b, __builtin_bit_cast(bf16x2_t, v.w), 1.0f, true);
+  return make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+}
+
+template <int NTW, int EPI>
+__global__ __launch_bounds__(256) void gemm3_rows_f8_kernel(Gemm3Dev p) {
+  __shared__ uint2 xs[4 * 64];  // one 32-k chunk of 4 row tiles as fp8 B fragments
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int nchunks = p.K >> 5;
+  const int mtile0 = blockIdx.y * 4;
+  const int tile0 = (blockIdx.x * 4 + wave) * NTW;
+  // thread (mt = wave, lane) stages the hi piece of row tile mtile0 + mt
+  const char* sp = ((mtile0 + wave) * 16 < p.M) ? p.x3 + (size_t)(mtile0 + wave) * nchunks * 3072 + lane * 16 : nullptr;
+  const char* wb[NTW];
+  bool wv[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    wv[t] = (tile0 + t) * 16 < p.N;
+    wb[t] = p.w + (size_t)(tile0 + t) * nchunks * 512 + lane * 8;
+  }
+  f32x4 acc[NTW][4];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  uint4 stage;
+  uint2 wnext[NTW];
+  auto fetch = [&](int c) {
+    stage = sp ? *reinterpret_cast<const uint4*>(sp + (size_t)c * 3072) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) wnext[t] = wv[t] ? *reinterpret_cast<const uint2*>(wb[t] + (size_t)c * 512) : make_uint2(0, 0);
+  };
+  fetch(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();  // previous chunk fully consumed
+    xs[tid] = bf16x8_to_fp8x8(stage);
+    long a[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) a[t] = __builtin_bit_cast(long, wnext[t]);
+    __syncthreads();
+    if (c + 1 < nchunks) fetch(c + 1);  // next chunk's loads fly under this chunk's MFMAs
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const long b = __builtin_bit_cast(long, xs[mt * 64 + lane]);
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a[t], b, acc[t][mt], 0, 0, 0);
+    }
+  }
+  rows_epilogue<NTW, EPI, true>(p, acc, mtile0, tile0, r, q);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -931,7 +1003,11 @@ static int launch3_rows(const Gemm3Dev& d, hipStream_t stream) {
   while (NTW > 1 && ((ntiles + 4 * NTW - 1) / (4 * NTW)) * row_blocks < 256) NTW >>= 1;
   const dim3 grid((ntiles + 4 * NTW - 1) / (4 * NTW), row_blocks);
   ST_REQUIRE(grid.y <= 65535, SMOLTTS_E_INVALID, "gemm3: M=%d too large for one launch", d.M);
-  if (NTW == 4) hipLaunchKernelGGL((gemm3_rows_kernel<4, EPI, W8>), grid, dim3(256), 0, stream, d);
+  if (W8 && d.f8_act) {  // fp8 x fp8 MFMA (opt-in: SmolttsGemm3Args.fp8_activations)
+    if (NTW == 4) hipLaunchKernelGGL((gemm3_rows_f8_kernel<4, EPI>), grid, dim3(256), 0, stream, d);
+    else if (NTW == 2) hipLaunchKernelGGL((gemm3_rows_f8_kernel<2, EPI>), grid, dim3(256), 0, stream, d);
+    else hipLaunchKernelGGL((gemm3_rows_f8_kernel<1, EPI>), grid, dim3(256), 0, stream, d);
+  } else if (NTW == 4) hipLaunchKernelGGL((gemm3_rows_kernel<4, EPI, W8>), grid, dim3(256), 0, stream, d);
   else if (NTW == 2) hipLaunchKernelGGL((gemm3_rows_kernel<2, EPI, W8>), grid, dim3(256), 0, stream, d);
   else hipLaunchKernelGGL((gemm3_rows_kernel<1, EPI, W8>), grid, dim3(256), 0, stream, d);
   ST_CHECK_HIP(hipGetLastError());
@@ -1022,6 +1098,7 @@ static int launch_gemm3_impl(const SmolttsGemm3Args& a, hipStream_t stream) {
   d.n_q_heads = a.n_q_heads; d.n_kv_heads = a.n_kv_heads; d.cache_len = a.cache_len;
   d.kv_bf16 = a.kv_format == SMOLTTS_KV_BF16;
   d.w_nt = a.w_stream != 0;
+  d.f8_act = a.fp8_activations != 0 && a.w_format == SMOLTTS_W_FP8;
   d.v_x3 = a.epilogue == SMOLTTS_EPI_QKV_ROPE ? (char*)a.v_x3_dev : nullptr;
   d.cand = a.epilogue == SMOLTTS_EPI_STORE ? a.cand_out_dev : nullptr;
 #ifdef SMOLTTS_DEBUG_HOOKS

@@ -97,6 +97,7 @@ struct SmolttsSession {
   bool split_attn;             // slow attention of few rows over two workgroups per (row, kv head) (SMOLTTS_OPT_SPLIT_ATTN)
   int stream_w;                // which weights of a decode frame are loaded with the non-temporal hint (SMOLTTS_OPT_STREAM_W, bit mask)
   bool fuse_depth_attn;        // depth attention worked out inside the wo launch (SMOLTTS_OPT_FUSE_DEPTH_ATTN)
+  bool fp8_prefill;            // prompt rows (M >= 256) of an fp8 engine on the fp8 x fp8 MFMA (SMOLTTS_OPT_FP8_PREFILL; not the parity path)
   bool fuse_pick;              // greedy depth codes picked inside the next step's layer-0 attention + wo launch (SMOLTTS_OPT_FUSE_PICK)
   float* cand;                 // [B][codebook_size / 16][4]: the depth head GEMM's tile candidates for that pick
   float* cand_slow;            // [B][vocab_size / 16][4]: the slow head GEMM's, for the commit kernel's greedy pick
@@ -371,6 +372,7 @@ int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, i
   const float eps = e->cfg.norm_eps;
   if (!qkv_done) {  // RMSNorm scale + QKV + RoPE + cache write
     SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.wqkv, in_x3, M, (n_head + 2 * n_kv) * 64, dim, SMOLTTS_EPI_QKV_ROPE);
+    a.fp8_activations = s->fp8_prefill;
     a.ssq_in_dev = s->ssq; a.eps = eps; a.out_dev = q; a.ldo = n_head * 64;
     a.rope_dev = rope; a.row_pos_dev = row_pos; a.row_slot_dev = row_slot;
     a.k_cache_dev = (float*)kc; a.v_cache_dev = (float*)vc; a.n_q_heads = n_head; a.n_kv_heads = n_kv; a.cache_len = cache_len;
@@ -390,6 +392,7 @@ int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, i
   }
   {  // x += attn . Wo^T ; publish x * ffn_norm for w1|w3
     SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.wo, s->x3a, M, dim, dim, SMOLTTS_EPI_RESID);
+    a.fp8_activations = s->fp8_prefill;
     a.resid_dev = x; a.out_dev = x; a.ldo = dim;
     a.emit_a_dev = s->x3n; a.gamma_a_dev = (const float*)(A + bw.ffn_norm); a.ssq_out_dev = s->ssq; a.w_stream = (w_stream & (1 | SMOLTTS_STREAM_W_DEPTH_QKVO)) != 0;
     if (fused_attn) {
@@ -402,11 +405,13 @@ int run_block(const SmolttsSession* s, const SmolttsBlockWeights& bw, int dim, i
   }
   {  // h = silu(w1 n) * (w3 n), n = RMSNorm(x); written as w2's operand
     SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.w13, s->x3n, M, 2 * inter, dim, SMOLTTS_EPI_SWIGLU);
+    a.fp8_activations = s->fp8_prefill;
     a.ssq_in_dev = s->ssq; a.eps = eps; a.x3_out_dev = s->x3h; a.w_stream = (w_stream & (1 | SMOLTTS_STREAM_W_DEPTH_W13)) != 0;
     ST_TRY(launch_gemm3_m(s, a, st));
   }
   {  // x += h . W2^T ; publish for the next consumer(s)
     SmolttsGemm3Args a = base3(e->cfg.weight_format, A + bw.w2, s->x3h, M, dim, inter, SMOLTTS_EPI_RESID);
+    a.fp8_activations = s->fp8_prefill;
     a.resid_dev = x; a.out_dev = x; a.ldo = dim;
     a.emit_a_dev = next.x3a; a.gamma_a_dev = next.gamma_a; a.emit_b_dev = next.x3b; a.gamma_b_dev = next.gamma_b;
     a.ssq_out_dev = next.ssq; a.w_stream = (w_stream & (1 | SMOLTTS_STREAM_W_DEPTH_W2)) != 0;
@@ -1123,6 +1128,7 @@ int smoltts_session_set_option(SmolttsSession* s, int32_t option, int32_t value)
     case SMOLTTS_OPT_STREAM_W: s->stream_w = value; break;
     case SMOLTTS_OPT_FUSE_DEPTH_ATTN: s->fuse_depth_attn = value != 0; break;
     case SMOLTTS_OPT_FUSE_PICK: s->fuse_pick = value != 0; break;
+    case SMOLTTS_OPT_FP8_PREFILL: s->fp8_prefill = value != 0; break;
     default:
       set_error("session_set_option: unknown option %d", option);
       return SMOLTTS_E_INVALID;
@@ -1165,6 +1171,14 @@ int smoltts_session_outputs(SmolttsSession* s, int32_t** codes_dev, int32_t** n_
   if (n_frames_dev) *n_frames_dev = s->frames;
   if (done_dev) *done_dev = s->done;
   if (margin_dev) *margin_dev = s->margin;
+  return SMOLTTS_OK;
+}
+
+int smoltts_session_kv_cache(SmolttsSession* s, void** k_dev, void** v_dev, uint64_t* layer_bytes) {
+  ST_REQUIRE(s && k_dev && v_dev && layer_bytes, SMOLTTS_E_INVALID, "session_kv_cache: null argument");
+  const SmolttsLMConfig& c = s->e->cfg;
+  *k_dev = s->kc; *v_dev = s->vc;
+  *layer_bytes = (uint64_t)s->B * c.n_kv_head * s->max_seq * 64 * (s->kv_format == SMOLTTS_KV_BF16 ? 2 : 4);
   return SMOLTTS_OK;
 }
 

@@ -104,7 +104,7 @@ _EXPORTS = [
     "smoltts_mimi_slab_bytes", "smoltts_mimi_session_create", "smoltts_mimi_session_destroy", "smoltts_mimi_reset",
     "smoltts_mimi_decode_chunk", "smoltts_k_gemm", "smoltts_k_attention", "smoltts_k_embed", "smoltts_k_argmax",
     "smoltts_k_layernorm", "smoltts_k_gemm3", "smoltts_k_x3_pack",
-    "smoltts_session_measure_duplicate", "smoltts_session_margin_at", "smoltts_session_drop_graph", "smoltts_session_set_frames_per_graph", "smoltts_engine_fast_qkv_bytes", "smoltts_engine_build_fast_qkv", "smoltts_session_set_option", "smoltts_gemm3_attn_fusable", "smoltts_lm_park_slots", "smoltts_lm_prefill_side", "smoltts_lm_start_slots", "smoltts_k_attention_split", "smoltts_k_attention_rows3",
+    "smoltts_session_measure_duplicate", "smoltts_session_margin_at", "smoltts_session_drop_graph", "smoltts_session_set_frames_per_graph", "smoltts_engine_fast_qkv_bytes", "smoltts_engine_build_fast_qkv", "smoltts_session_set_option", "smoltts_gemm3_attn_fusable", "smoltts_lm_park_slots", "smoltts_lm_prefill_side", "smoltts_lm_start_slots", "smoltts_session_kv_cache", "smoltts_k_attention_split", "smoltts_k_attention_rows3",
     "smoltts_session_slab_bytes_kv", "smoltts_session_create_kv", "smoltts_k_attention_kv", "smoltts_session_set_sampling", "smoltts_k_sample",
     "smoltts_lm_prefill_chunk", "smoltts_lm_prefill_deferred", "smoltts_mimi_reset_slots", "smoltts_mimi_encoder_create", "smoltts_mimi_encoder_destroy", "smoltts_mimi_encode_frames",
     "smoltts_mimi_encode_workspace_bytes", "smoltts_mimi_encode",
@@ -295,7 +295,7 @@ def _fill_block(dst: BlockWeights, src: Dict[str, int]) -> None:
         setattr(dst, k, v)
 
 
-OPT_QKV_TABLE, OPT_COMMIT_PICKS, OPT_SPLIT_ATTN, OPT_STREAM_W, OPT_FUSE_DEPTH_ATTN, OPT_FUSE_PICK = 1, 2, 3, 4, 5, 6  # include/smoltts_hip.h SMOLTTS_OPT_*
+OPT_QKV_TABLE, OPT_COMMIT_PICKS, OPT_SPLIT_ATTN, OPT_STREAM_W, OPT_FUSE_DEPTH_ATTN, OPT_FUSE_PICK, OPT_FP8_PREFILL = 1, 2, 3, 4, 5, 6, 7  # include/smoltts_hip.h SMOLTTS_OPT_*
 
 
 class LMEngine:
@@ -410,6 +410,8 @@ class LMSession:
             self.use_fused_depth_attention(False)
         if os.environ.get("SMOLTTS_FUSE_PICK") == "0":
             self.use_fused_pick(False)
+        if os.environ.get("SMOLTTS_FP8_PREFILL") == "1":  # (bench.py --fp8-prefill: not the parity path)
+            self.use_fp8_prefill(True)
         if os.environ.get("SMOLTTS_STREAM_W") is not None:  # mask of SMOLTTS_STREAM_W_* bits
             check(self.lib.smoltts_session_set_option(self.handle, OPT_STREAM_W, int(os.environ["SMOLTTS_STREAM_W"])), "smoltts_session_set_option")
 
@@ -539,6 +541,25 @@ class LMSession:
     def use_fused_depth_attention(self, on: bool) -> None:
         """Depth steps 1..: attention over the <= 8-entry cache inside the wo launch (default) or as a launch of its own."""
         check(self.lib.smoltts_session_set_option(self.handle, OPT_FUSE_DEPTH_ATTN, 1 if on else 0), "smoltts_session_set_option")
+
+    def kv_cache(self):
+        """(K, V) views of the slow transformer's cache: [n_layer, max_batch, n_kv_head, max_seq, 64] in the session's kv dtype (diagnostics)."""
+        k, v, lb = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        check(self.lib.smoltts_session_kv_cache(self.handle, C.byref(k), C.byref(v), C.byref(lb)), "smoltts_session_kv_cache")
+        cfg = self.engine.cfg
+        n_layer, kvh = cfg.n_layer, cfg.n_local_heads
+        dt = torch.float32 if lb.value == self.B * kvh * self.max_seq * 64 * 4 else torch.bfloat16
+        base = self.slab.data_ptr()
+        out = []
+        for p in (k, v):
+            o = p.value - base
+            out.append(self.slab[o: o + n_layer * lb.value].view(dt).view(n_layer, self.B, kvh, self.max_seq, 64))
+        return out
+
+    def use_fp8_prefill(self, on: bool) -> None:
+        """fp8-weight engines: prompt prefills of >= 256 rows on the fp8 x fp8 MFMA (BASELINE configs[4]'s fp8 MFMA prefill).  Faster
+        first chunk; the prompt's KV rows carry the activations' fp8 rounding, so ids may leave the reference greedy decode."""
+        check(self.lib.smoltts_session_set_option(self.handle, OPT_FP8_PREFILL, 1 if on else 0), "smoltts_session_set_option")
 
     def use_fused_pick(self, on: bool) -> None:
         """Greedy depth codes picked inside the next step's layer-0 attention + wo launch (default) or by a launch of their own."""

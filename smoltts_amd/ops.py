@@ -223,7 +223,7 @@ class Gemm3Args(C.Structure):
         ("kv_format", C.c_int32),
         ("w_stream", C.c_int32),
         ("attn_q_dev", C.c_void_p), ("attn_pos", C.c_int32),
-        ("cand_out_dev", C.c_void_p), ("pick", C.c_void_p),
+        ("cand_out_dev", C.c_void_p), ("pick", C.c_void_p), ("fp8_activations", C.c_int32),
     ]
 
 
@@ -243,7 +243,8 @@ def linear3(x3: torch.Tensor, w_tiles: torch.Tensor, M: int, N: int, K: int, *, 
             ssq_out: Optional[torch.Tensor] = None, rope=None, row_pos=None, row_slot=None, k_cache=None, v_cache=None,
             n_q_heads: int = 0, n_kv_heads: int = 0, cache_len: int = 0, w_scale: Optional[torch.Tensor] = None,
             v_x3: Optional[torch.Tensor] = None, kv_format: int = 0, w_stream: bool = False,
-            attn_q: Optional[torch.Tensor] = None, attn_pos: int = 0, cand_out: Optional[torch.Tensor] = None):
+            attn_q: Optional[torch.Tensor] = None, attn_pos: int = 0, cand_out: Optional[torch.Tensor] = None,
+            fp8_activations: bool = False):
     """The bf16-MFMA GEMM over an X3 operand; returns the fp32 ``out`` tensor (None for SWIGLU).
     ``w_scale`` given: ``w_tiles`` are e4m3 tiles (``pack_weight_fp8``).
     ``attn_q`` given (EPI_RESID): ``x3`` may be None -- the operand is the attention of ``attn_q`` over keys 0..``attn_pos`` of
@@ -269,6 +270,7 @@ def linear3(x3: torch.Tensor, w_tiles: torch.Tensor, M: int, N: int, K: int, *, 
     a.kv_format = int(kv_format)
     a.w_stream = 1 if w_stream else 0
     a.attn_q_dev, a.attn_pos = E.dptr(attn_q), int(attn_pos)
+    a.fp8_activations = 1 if fp8_activations else 0  # fp8 weights, M >= 256: fp8 x fp8 MFMA on the activation's hi piece (not the parity path)
     a.cand_out_dev = E.dptr(cand_out)  # EPI_STORE: per (row, 16-column tile) (max, first column of it as int bits, runner-up, -)
     E.check(lib.smoltts_k_gemm3(C.byref(a), E.current_stream_ptr()), "smoltts_k_gemm3")
     return out

@@ -170,3 +170,76 @@ def test_fp8_through_the_facade():
     keep = (grid[0] >= 320) & (grid[0] <= 2367)
     ref = MimiDecodeOracle(mst).decode(grid[1:, keep][None])[0, 0].numpy()
     assert pcm.shape == ref.shape and float(np.sqrt(np.mean((pcm - ref) ** 2))) <= 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 768, 768), (300, 6144, 768), (1000, 768, 3072)])
+def test_fp8_mfma_prefill_gemm_is_the_fp8_product_exactly(E, ops, M, N, K):
+    """SmolttsGemm3Args.fp8_activations (BASELINE configs[4]'s "fp8 MFMA prefill", M >= 256): e4m3 weight tiles x the activation's
+    leading bf16 piece rounded to e4m3 on v_mfma_f32_16x16x32_fp8_fp8.  Products of two e4m3 values are exact in fp32, so the
+    launch must equal the same product in PyTorch up to the fp32 summation order; against the unquantised activations it is an
+    approximation (that is why it is an option, not the parity path)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g) * 3.0
+    w = torch.randn(N, K, generator=g) * 0.05
+    gamma = 1 + 0.1 * torch.randn(K, generator=g)
+    wt, scale, wdq = ops.pack_weight_fp8(w)
+    x3, _, ssq = ops.x3_pack(x.cuda(), gamma.cuda())
+    out = ops.linear3(x3, wt, M, N, K, ssq_in=ssq, w_scale=scale, fp8_activations=True).cpu()
+    xg = (x * gamma).bfloat16()  # the operand's leading piece
+    x8 = xg.to(torch.float8_e4m3fn).float()
+    rstd = torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-5)
+    ref8 = (x8.double() @ wdq.double().T).float() * rstd
+    assert rel_err(out, ref8) < 5e-5  # (fp32 accumulation of up to 3072 exact products in one wave)
+    exact = rms_norm_ref(x, gamma, 1e-5) @ wdq.T
+    err = rel_err(out, exact)
+    assert 1e-4 < err < 3e-2, err  # an approximation of the exact product, of the size fp8 activations give
+    # ... and the default (exact) path of the same call is untouched by the flag's existence
+    out_exact = ops.linear3(x3, wt, M, N, K, ssq_in=ssq, w_scale=scale).cpu()
+    assert rel_err(out_exact, exact) < 2e-5
+
+
+def test_fp8_mfma_prefill_in_the_engine():
+    """SMOLTTS_OPT_FP8_PREFILL: a prompt batch of >= 256 rows through the fp8 MFMA kernels, then the ordinary decode.  What the option
+    changes is the prompt's KV rows: they must be an approximation of the exact prefill's of the size fp8 activations give (~3 % of the rows' RMS
+    behind one GEMM) and not equal to them; the decode behind them runs to the end inside the tables.  Ids are NOT compared for equality: with random weights
+    (near-flat logits) the approximate prompt changes most of them -- which is why the option is off by default."""
+    from smoltts_amd.config import TokenConfig
+    from smoltts_amd.engine import LMEngine, LMSession
+    from smoltts_amd.prompt import PromptEncoder
+    from smoltts_amd.synthetic import named_config, synthetic_lm_state
+    from smoltts_amd.tokenizer import load_tokenizer
+
+    cfg = named_config("smoltts_byte_70m")
+    tok = load_tokenizer()
+    tc = TokenConfig.from_tokenizer(tok, cfg)
+    eng = LMEngine(cfg, synthetic_lm_state(cfg, seed=3), tc, weight_format="fp8")
+    pe = PromptEncoder(tok, tc.semantic_start_id)
+    prompts = [pe.build_prompt("prompt number %d of a batch that is long enough for the many-row kernels" % i, "heart") for i in range(8)]
+    T = min(p.shape[1] for p in prompts)
+    assert sum(p.shape[1] for p in prompts) >= 256
+    res, kv = {}, {}
+    for on in (False, True):
+        s = LMSession(eng, max_batch=8, max_seq=256, max_rows=1024, max_frames=8)
+        s.use_fp8_prefill(on)
+        s.prefill(prompts, stop_on_eos=False)
+        torch.cuda.synchronize()
+        k, v = s.kv_cache()
+        kv[on] = (k[:, :, :, : T - 1].float().cpu(), v[:, :, :, : T - 1].float().cpu())  # the prompt rows every slot has
+        s.decode(7)
+        codes, n, _, _ = s.fetch()
+        assert (n == 8).all() and codes[:, :8, 0].max() < cfg.vocab_size and codes[:, :8, 1:].max() < cfg.codebook_size and codes.min() >= 0
+        res[on] = codes[:, :8].copy()
+        s.close()
+    for i, name in enumerate(("K", "V")):
+        a, b = kv[False][i], kv[True][i]
+        assert torch.isfinite(b).all()
+        err = float((a - b).pow(2).mean().sqrt() / a.pow(2).mean().sqrt())
+        print(f"fp8 MFMA prefill: prompt {name} rows differ from the exact prefill's by {err:.2e} of their RMS (layer 0: "
+              f"{float((a[0] - b[0]).pow(2).mean().sqrt() / a[0].pow(2).mean().sqrt()):.2e}, last layer: "
+              f"{float((a[-1] - b[-1]).pow(2).mean().sqrt() / a[-1].pow(2).mean().sqrt()):.2e})")
+        e0 = float((a[0] - b[0]).pow(2).mean().sqrt() / a[0].pow(2).mean().sqrt())
+        # e4m3 activations carry 2^-4 relative rounding per element, and a sum of randomly signed terms keeps that relative error:
+        # ~3 % behind one GEMM (layer 0), growing through the layers (~15 % at layer 9 with random weights)
+        assert 1e-3 < e0 < 6e-2 and err < 0.3, (e0, err)
+    print(f"fp8 MFMA prefill: {100 * float((res[True] == res[False]).mean()):.1f} % of the first 8 frames' ids equal the exact prefill's")
+    eng.close()
