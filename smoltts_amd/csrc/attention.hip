@@ -234,7 +234,10 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
 // (MI355X_MICROARCH.md "Valid forms", first table row: one lane adds to one counter behind the storing wave's vmcnt(0); the
 // workgroup whose add returned last loads, all loads sc1).  Tickets count up across launches (NS arrivals per pair and launch).
 constexpr int ATT_PS_PAD = 8;  // floats behind the G * 64 sums of a record: (max, denominator) per head
-constexpr int ATT_SPLIT_MIN_KEYS = 512;  // rows with fewer cached keys run on one workgroup
+#ifndef SMOLTTS_ATT_SPLIT_MIN_KEYS  // (timing variants: tools/ab_lib.sh; round 4 re-checked 256 / 384 / 768 against 512)
+#define SMOLTTS_ATT_SPLIT_MIN_KEYS 512
+#endif
+constexpr int ATT_SPLIT_MIN_KEYS = SMOLTTS_ATT_SPLIT_MIN_KEYS;  // rows with fewer cached keys run on one workgroup
 
 template <int LPK>
 __device__ __forceinline__ float group_sum(float x) {  // sum over the LPK (8 or 16) lanes of a key's lane group, result in every lane
