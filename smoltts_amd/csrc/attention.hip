@@ -263,17 +263,23 @@ __device__ __forceinline__ void load_kv_lane(const void* base, long e, bool ok, 
 }
 
 template <int G, bool KB, int NS>
-__global__ __launch_bounds__(1024) void attn_split_kernel(AttnDev p) {
+__global__ __launch_bounds__(1024) void attn_split_kernel(const int* row_pos_, const int* row_slot_, const float* q_, const void* kc_, const void* vc_,
+                                                         int heads_, int cache_len_, int nwaves, AttnDev p) {
+  // the head of the dependent chain (row -> position -> cache rows) in SGPRs at wave launch: common.h, kernarg_touch
+  KernargTouch<2> kt;
+  kernarg_touch(kt);
+  p.row_pos = row_pos_; p.row_slot = row_slot_; p.q = q_; p.kc = kc_; p.vc = vc_;
+  p.n_q_heads = heads_ & 0xffff; p.n_kv_heads = heads_ >> 16; p.cache_len = cache_len_;
   constexpr int LPK = KVLane<KB>::LPK, DPL = KVLane<KB>::DPL, KPI = 64 / LPK;  // lanes per key, dims per lane, keys per wave-instruction
   constexpr int PS = G * 64 + ATT_PS_PAD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int nwaves = blockDim.x >> 6;
   float* part = smem;                  // [16 waves][G][64]
   float* stat = smem + 16 * G * 64;    // [16 waves][G][2] (max, sum)
   const int row = blockIdx.x, h = blockIdx.y, prt = NS > 1 ? (int)blockIdx.z : 0;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int kk = lane / LPK, dl = lane % LPK;
   const int pos = p.row_pos[row], slot = p.row_slot[row];
+  kernarg_touched(kt);
   const int HD = p.n_q_heads * 64;
   // A row whose position lies outside the cache has nothing to attend to.  This guard stands in front of every use of `pos`: the
   // cache reads below are the only accesses of this kernel whose address depends on an unvalidated input, and for pos >= cache_len
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(1024) void attn_split_kernel(AttnDev p) {
   // tests/test_attn_split_gpu.py covers pos = -1, cache_len, cache_len + 7.
   if (pos < 0 || pos >= p.cache_len) {
     if (prt == 0)
-      for (int i = tid; i < G * 16; i += blockDim.x) {
+      for (int i = tid; i < G * 16; i += nwaves * 64) {
         const int k = (h * G + (i >> 4)) * 64 + (i & 15) * 4;
         if (p.out) *reinterpret_cast<float4*>(p.out + (long)row * HD + k) = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.out_x3) x3_emit4(p.out_x3, row, k, HD >> 5, 0.f, 0.f, 0.f, 0.f);
@@ -1010,11 +1016,12 @@ int launch_attention(const float* q, const void* kc, const void* vc, const int32
   if (kb || can_split) {
     const int NS = can_split ? 2 : 1;
     const dim3 sgrid(n_rows, n_kv_heads, NS);
+#define SPLIT_ARGS d.row_pos, d.row_slot, d.q, d.kc, d.vc, d.n_q_heads | (d.n_kv_heads << 16), d.cache_len, nwaves, d
 #define ST_SPLIT(GG)                                                                                                              \
   case GG:                                                                                                                          \
-    if (kb && NS == 2) hipLaunchKernelGGL((attn_split_kernel<GG, true, 2>), sgrid, dim3(nwaves * 64), lds, stream, d);              \
-    else if (kb) hipLaunchKernelGGL((attn_split_kernel<GG, true, 1>), sgrid, dim3(nwaves * 64), lds, stream, d);                    \
-    else hipLaunchKernelGGL((attn_split_kernel<GG, false, 2>), sgrid, dim3(nwaves * 64), lds, stream, d);                           \
+    if (kb && NS == 2) hipLaunchKernelGGL((attn_split_kernel<GG, true, 2>), sgrid, dim3(nwaves * 64), lds, stream, SPLIT_ARGS);              \
+    else if (kb) hipLaunchKernelGGL((attn_split_kernel<GG, true, 1>), sgrid, dim3(nwaves * 64), lds, stream, SPLIT_ARGS);                    \
+    else hipLaunchKernelGGL((attn_split_kernel<GG, false, 2>), sgrid, dim3(nwaves * 64), lds, stream, SPLIT_ARGS);                           \
     break;
     ST_REQUIRE(lds <= 64 * 1024, SMOLTTS_E_CAPACITY, "attention: %zu bytes of LDS", lds);
     switch (G) {
@@ -1027,6 +1034,7 @@ int launch_attention(const float* q, const void* kc, const void* vc, const int32
         return SMOLTTS_E_INVALID;
     }
 #undef ST_SPLIT
+#undef SPLIT_ARGS
     ST_CHECK_HIP(hipGetLastError());
     return SMOLTTS_OK;
   }

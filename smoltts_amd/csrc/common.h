@@ -77,6 +77,33 @@ inline int device_cu_count() {  // CUs of the current device (cached per device)
 __device__ __forceinline__ float bf16_lo(uint32_t dw) { return __uint_as_float(dw << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t dw) { return __uint_as_float(dw & 0xffff0000u); }
 
+// The kernel arguments of a frame's launches sit in memory nothing has touched since the graph's last replay: every 64-byte line
+// of them a kernel reads is a miss of its own (to the fabric: ~0.5 us), and the compiler asks for each where it is first used,
+// one after the other.  kernarg_touch() asks for one dword of each of the lines 1 .. LINES at the kernel's first instruction, all
+// misses in flight at once (line 0 holds the leading scalar arguments, which arrive in SGPRs: build.py's
+// -amdgpu-kernarg-preload-count); kernarg_touched() ends the dwords' lifetime behind an s_waitcnt.  The later reads of the
+// compiler's own code hit the scalar cache.
+template <int LINES>
+struct KernargTouch {
+  unsigned t[LINES];
+};
+template <int LINES>
+__device__ __forceinline__ void kernarg_touch(KernargTouch<LINES>& k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+#pragma unroll
+  for (int i = 0; i < LINES; ++i) asm volatile("s_load_dword %0, %1, %2" : "=s"(k.t[i]) : "s"(ka), "i"(64 * (i + 1)));
+#endif
+}
+template <int LINES>
+__device__ __forceinline__ void kernarg_touched(KernargTouch<LINES>& k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < LINES; ++i) asm volatile("" : "+s"(k.t[i]));  // the registers stay reserved up to here
+#endif
+}
+
 // Host-side description of where a producer of the residual stream publishes it for the next GEMM(s)
 // (device form: EmitDev in x3.h).
 struct EmitArgs {

@@ -68,6 +68,10 @@ struct Gemm3Dev {
   unsigned long long* stamps;  // diagnostics only (smoltts_debug_set_stamps); nullptr in production
 };
 
+// 64-byte lines of kernel arguments behind the first: 7 leading scalars (0x28 bytes) + Gemm3Dev
+constexpr int G3_KERNARG_LINES = (0x28 + (int)sizeof(Gemm3Dev) - 1) / 64;
+constexpr int AWO_KERNARG_LINES = (0x38 + (int)sizeof(Gemm3Dev) - 1) / 64;  // attn_wo_kernel: 14 dwords in front
+
 #ifdef SMOLTTS_DEBUG_HOOKS  // diagnostic builds only (python -m smoltts_amd.build --variant hooks): never in the product library
 #define STAMP3(k)                                                                             \
   do {                                                                                        \
@@ -129,10 +133,14 @@ __device__ __forceinline__ bf16x8_t wfrag_bf16(uint4 v) {
 __device__ __forceinline__ float silu3(float x) { return x / (1.f + expf(-x)); }
 
 template <int MT, int T, int U, int EPI, bool W8, bool NT = false>  // NT: weight loads with the non-temporal hint (Gemm3Dev.w_nt)
-__global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
+__global__ __launch_bounds__(512) void gemm3_kernel(const char* w_, const char* x3_, int M_, int N_, int K_, int half_rows_, int nwaves, Gemm3Dev p) {
+  // what the first loads need comes as leading scalar arguments (preloaded into SGPRs at wave launch: build.py's
+  // -amdgpu-kernarg-preload-count), the rest is read from the kernarg segment behind them (common.h: kernarg_touch)
+  KernargTouch<G3_KERNARG_LINES> kt;
+  kernarg_touch(kt);
+  p.w = w_; p.x3 = x3_; p.M = M_; p.N = N_; p.K = K_; p.half_rows = half_rows_;
   constexpr int WTILE = W8 ? 512 : 1024, WLANE = W8 ? 8 : 16;  // bytes per weight tile-chunk / per lane
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int nwaves = blockDim.x >> 6;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 15, q = lane >> 4;
   const int ng = blockIdx.x;
@@ -195,6 +203,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Dev p) {
   };
   // the operand stream goes out first ...
   load_group(wave);
+  kernarg_touched(kt);
 
   // ... then the epilogue inputs of the finishing waves, all issued here so that the tail of the
   // kernel waits on nothing
@@ -783,7 +792,15 @@ __device__ __forceinline__ void awo_compute(const AwoUnit<G, TWO>& u, char* frag
 constexpr int AWO_NA = 4, AWO_NB = 8, AWO_U = 3;  // attention waves, GEMM waves, 32-k chunks per GEMM wave (K <= 768)
 
 template <int G, int T, bool TWO, bool W8, bool PICK>  // TWO: more than 4 keys (a second key per lane); PICK: SmolttsPickArgs
-__global__ __launch_bounds__(768) void attn_wo_kernel(Gemm3Dev p) {
+__global__ __launch_bounds__(768) void attn_wo_kernel(const char* w_, const float* kc_, const float* vc_, const float* q_or_cand, const float* pk_table_,
+                                                      int m_tiles, int N_, int K_, int heads_pos, Gemm3Dev p) {
+  // 14 dwords of leading scalar arguments = what the first loads of both kinds of waves need, in SGPRs at wave launch (see gemm3_kernel)
+  KernargTouch<AWO_KERNARG_LINES> kt;
+  kernarg_touch(kt);
+  p.w = w_; p.kc = const_cast<float*>(kc_); p.vc = const_cast<float*>(vc_); p.pk_table = pk_table_;
+  if (PICK) p.pk_cand = q_or_cand; else p.aq = q_or_cand;
+  p.M = m_tiles & 0xffff; p.pk_tiles = m_tiles >> 16; p.N = N_; p.K = K_;
+  p.n_q_heads = heads_pos & 255; p.n_kv_heads = (heads_pos >> 8) & 255; p.cache_len = (heads_pos >> 16) & 255; p.a_pos = heads_pos >> 24;
   constexpr int WTILE = W8 ? 512 : 1024, WLANE = W8 ? 8 : 16;
   constexpr int R = AWO_R, NA = AWO_NA, NB = AWO_NB, U = AWO_U;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -823,6 +840,7 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(Gemm3Dev p) {
     }
     AwoUnit<G, TWO> un;
     if (wave < n_units) awo_load<G, TWO, PICK>(un, p, wave, kv_pairs, row0, lane, wave / kv_pairs ? erow1 : erow0, blockIdx.x == 0);
+    kernarg_touched(kt);
     // epilogue inputs of the finishing waves (wave f: column tile f): in flight across phase A, the barriers and the K loop
     const bool fin = wave < T;
     const int tf = fin ? wave : 0;
@@ -928,6 +946,7 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(Gemm3Dev p) {
                                                    : make_uint4(0, 0, 0, 0);
     }
   }
+  kernarg_touched(kt);
   STAMP3(5);
   __syncthreads();  // the fragments are in LDS
   const bool row_on = r < R;
@@ -970,7 +989,12 @@ static int launch_attn_wo_g(const Gemm3Dev& d, hipStream_t stream) {
   const size_t lds = (size_t)nchunks * 3 * 4 * AWO_R * 16 + (size_t)AWO_NB * T * 1024;
   const bool two = d.a_pos + 1 > 4;
   const dim3 block((AWO_NA + AWO_NB) * 64);
-#define ST_AWO(TT, TWO_, PK_) hipLaunchKernelGGL((attn_wo_kernel<G, TT, TWO_, W8, PK_>), grid, block, lds, stream, d)
+  ST_REQUIRE(d.M < 65536 && d.pk_tiles < 32768 && d.n_q_heads < 256 && d.cache_len < 256 && d.a_pos < 128, SMOLTTS_E_INVALID,
+             "gemm3: attention + wo: sizes out of the packed arguments' range");
+  const int m_tiles = d.M | (d.pk_tiles << 16), heads_pos = d.n_q_heads | (d.n_kv_heads << 8) | (d.cache_len << 16) | (d.a_pos << 24);
+#define ST_AWO(TT, TWO_, PK_)                                                                                                   \
+  hipLaunchKernelGGL((attn_wo_kernel<G, TT, TWO_, W8, PK_>), grid, block, lds, stream, d.w, (const float*)d.kc, (const float*)d.vc, \
+                     PK_ ? d.pk_cand : d.aq, d.pk_table, m_tiles, d.N, d.K, heads_pos, d)
   if (d.pk_cand) {
     if (T == 3) { if (two) ST_AWO(3, true, true); else ST_AWO(3, false, true); }
     else { if (two) ST_AWO(1, true, true); else ST_AWO(1, false, true); }
@@ -1020,8 +1044,9 @@ static int launch3_one(const Gemm3Dev& d, int nwaves, hipStream_t stream) {
   if (nwaves < MT * T) nwaves = MT * T;  // one finishing wave per (column tile, row tile) of the workgroup
   const dim3 grid((ntiles + T - 1) / T, ((d.M + 16 * MT - 1) / (16 * MT)) * (d.half_rows ? 2 : 1));
   const size_t lds = (size_t)nwaves * T * MT * 1024 + (size_t)MT * 16 * sizeof(float);  // partial tiles + the row scales
-  if (MT == 1 && d.w_nt) hipLaunchKernelGGL((gemm3_kernel<MT, T, U, EPI, W8, MT == 1>), grid, dim3(nwaves * 64), lds, stream, d);
-  else hipLaunchKernelGGL((gemm3_kernel<MT, T, U, EPI, W8>), grid, dim3(nwaves * 64), lds, stream, d);
+  if (MT == 1 && d.w_nt)
+    hipLaunchKernelGGL((gemm3_kernel<MT, T, U, EPI, W8, MT == 1>), grid, dim3(nwaves * 64), lds, stream, d.w, d.x3, d.M, d.N, d.K, d.half_rows, nwaves, d);
+  else hipLaunchKernelGGL((gemm3_kernel<MT, T, U, EPI, W8>), grid, dim3(nwaves * 64), lds, stream, d.w, d.x3, d.M, d.N, d.K, d.half_rows, nwaves, d);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
 }
