@@ -176,8 +176,8 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
   for (int g = 0; g < G; ++g) {
 #pragma unroll
     for (int o = 16; o <= 32; o <<= 1) {
-      const float om = __shfl_xor(mx[g], o), od = __shfl_xor(den[g], o);
-      const float ox = __shfl_xor(acc[g].x, o), oy = __shfl_xor(acc[g].y, o), oz = __shfl_xor(acc[g].z, o), ow = __shfl_xor(acc[g].w, o);
+      const float om = lane_xor_c(mx[g], o, lane), od = lane_xor_c(den[g], o, lane);
+      const float ox = lane_xor_c(acc[g].x, o, lane), oy = lane_xor_c(acc[g].y, o, lane), oz = lane_xor_c(acc[g].z, o, lane), ow = lane_xor_c(acc[g].w, o, lane);
       const float mn = fmaxf(mx[g], om);
       const float sa = mn > -INFINITY ? __expf(mx[g] - mn) : 0.f, sb = mn > -INFINITY ? __expf(om - mn) : 0.f;
       den[g] = den[g] * sa + od * sb;
@@ -426,12 +426,12 @@ __global__ __launch_bounds__(1024) void attn_split_kernel(const int* row_pos_, c
   for (int g = 0; g < G; ++g) {
 #pragma unroll
     for (int o = LPK; o <= 32; o <<= 1) {
-      const float om = __shfl_xor(mx[g], o), od = __shfl_xor(den[g], o);
+      const float om = lane_xor_c(mx[g], o, lane), od = lane_xor_c(den[g], o, lane);
       const float mn = fmaxf(mx[g], om);
       const float sa = mn > -INFINITY ? __expf(mx[g] - mn) : 0.f, sb = mn > -INFINITY ? __expf(om - mn) : 0.f;
       den[g] = den[g] * sa + od * sb;
 #pragma unroll
-      for (int i = 0; i < DPL; ++i) acc[g][i] = acc[g][i] * sa + __shfl_xor(acc[g][i], o) * sb;
+      for (int i = 0; i < DPL; ++i) acc[g][i] = acc[g][i] * sa + lane_xor_c(acc[g][i], o, lane) * sb;
       mx[g] = mn;
     }
     if (kk == 0) {

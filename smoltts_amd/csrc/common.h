@@ -77,6 +77,59 @@ inline int device_cu_count() {  // CUs of the current device (cached per device)
 __device__ __forceinline__ float bf16_lo(uint32_t dw) { return __uint_as_float(dw << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t dw) { return __uint_as_float(dw & 0xffff0000u); }
 
+// The value of lane ^ O, on the VALU: DPP inside a 16-lane row (O = 1, 2, 4, 8), v_permlane16_swap / v_permlane32_swap across
+// rows (gfx950).  __shfl_xor compiles to ds_bpermute_b32 -- a round trip through the LDS crossbar per step -- and the frame's
+// kernels end on two or four dependent ones (sums of squares, top-2 merges).  Exact lane ^ O in every case, so a reduction
+// keeps its order of additions.
+template <int O>
+__device__ __forceinline__ unsigned lane_xor_u(unsigned x, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (O == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // lower half: (own, partner's); upper: (partner's, own)
+    return (lane & 32) ? r[0] : r[1];
+  } else if constexpr (O == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    return (lane & 16) ? r[0] : r[1];
+  } else if constexpr (O == 8) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, true);  // row_ror:8
+  } else if constexpr (O == 4) {
+    const int y = __builtin_amdgcn_update_dpp(0, (int)x, 0x1B, 0xF, 0xF, true);  // quad_perm [3,2,1,0]: lane ^ 3
+    return (unsigned)__builtin_amdgcn_update_dpp(0, y, 0x141, 0xF, 0xF, true);   // row_half_mirror: lane ^ 7
+  } else if constexpr (O == 2) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+  } else {
+    static_assert(O == 1, "lane_xor: O must be a power of two below 64");
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+  }
+#else
+  return x;
+#endif
+}
+template <int O>
+__device__ __forceinline__ float lane_xor(float x, int lane) { return __uint_as_float(lane_xor_u<O>(__float_as_uint(x), lane)); }
+template <int O>
+__device__ __forceinline__ int lane_xor(int x, int lane) { return (int)lane_xor_u<O>((unsigned)x, lane); }
+__device__ __forceinline__ float lane_xor_c(float x, int o, int lane) {  // o: a constant once the caller's loop is unrolled
+  switch (o) {
+    case 32: return lane_xor<32>(x, lane);
+    case 16: return lane_xor<16>(x, lane);
+    case 8: return lane_xor<8>(x, lane);
+    case 4: return lane_xor<4>(x, lane);
+    case 2: return lane_xor<2>(x, lane);
+    default: return lane_xor<1>(x, lane);
+  }
+}
+// x + (lane ^ 16's x) + ... in the order `x += shfl_xor(x, 16); x += shfl_xor(x, 32)` (a + b == b + a: no lane select needed)
+__device__ __forceinline__ float sum_xor16_32(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+#endif
+  return x;
+}
+
 // The kernel arguments of a frame's launches sit in memory nothing has touched since the graph's last replay: every 64-byte line
 // of them a kernel reads is a miss of its own (to the fabric: ~0.5 us), and the compiler asks for each where it is first used,
 // one after the other.  kernarg_touch() asks for one dword of each of the lines 1 .. LINES at the kernel's first instruction, all

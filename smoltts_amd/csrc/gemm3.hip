@@ -286,8 +286,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const char* w_, const char* 
     const int nt_in = p.K >> 4;
     if (nt_in > 64 && mvalid)
       for (int i = 64 + q; i < nt_in; i += 4) sq += p.ssq_in[(size_t)m * nt_in + i];
-    sq += __shfl_xor(sq, 16);
-    sq += __shfl_xor(sq, 32);
+    sq = sum_xor16_32(sq);
     rstd = 1.0f / sqrtf(sq / (float)p.K + p.eps);
     if (NF > MT && q == 0) rstd_lds[fmt * 16 + r] = rstd;
   }
@@ -328,8 +327,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const char* w_, const char* 
       }
       if (p.emit.ssq) {  // all 64 lanes take part in the shuffles
         float sq = valid ? ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) : 0.f;
-        sq += __shfl_xor(sq, 16);
-        sq += __shfl_xor(sq, 32);
+        sq = sum_xor16_32(sq);
         if (q == 0 && mvalid && ntile * 16 < p.N) p.emit.ssq[(size_t)m * (p.N >> 4) + ntile] = sq;
       }
       if (EPI == SMOLTTS_EPI_STORE && p.cand) {  // (wave-uniform) the tile's top-2 per row: what a greedy pick needs of these logits
@@ -341,12 +339,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const char* w_, const char* 
             else if (v[i] > t.v2) t.v2 = v[i];
           }
         }
-#pragma unroll
-        for (int o = 16; o <= 32; o <<= 1) {  // the 4 lanes (q) that hold the row's 16 columns
-          Top2 b;
-          b.v1 = __shfl_xor(t.v1, o); b.i1 = __shfl_xor(t.i1, o); b.v2 = __shfl_xor(t.v2, o);
-          t = top2_merge(t, b);
-        }
+        t = top2_swap<false>(t, lane);  // the 4 lanes (q) that hold the row's 16 columns: lane ^ 16, then lane ^ 32
+        t = top2_swap<true>(t, lane);
         if (q == 0 && mvalid && ntile * 16 < p.N)
           *reinterpret_cast<float4*>(p.cand + ((size_t)m * ((p.N + 15) >> 4) + ntile) * 4) = make_float4(t.v1, __int_as_float(t.i1), t.v2, 0.f);
       }
@@ -403,8 +397,7 @@ __device__ __forceinline__ void rows_epilogue(const Gemm3Dev& p, f32x4 (&acc)[NT
       const float* ssp = p.ssq_in + (size_t)mc * nt_in;
       float s = 0.f;
       for (int i = q; i < nt_in; i += 4) s += ssp[i];
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
+      s = sum_xor16_32(s);
       rstd = 1.0f / sqrtf(s / (float)p.K + p.eps);
     }
     int pos = 0, slot = 0;
@@ -436,8 +429,7 @@ __device__ __forceinline__ void rows_epilogue(const Gemm3Dev& p, f32x4 (&acc)[NT
         }
         if (p.emit.ssq) {  // all 64 lanes take part in the shuffles
           float s = valid ? ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) : 0.f;
-          s += __shfl_xor(s, 16);
-          s += __shfl_xor(s, 32);
+          s = sum_xor16_32(s);
           if (q == 0 && mvalid && ntile * 16 < p.N) p.emit.ssq[(size_t)m * (p.N >> 4) + ntile] = s;
         }
       } else if (EPI == SMOLTTS_EPI_SWIGLU) {
@@ -921,8 +913,7 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(const char* w_, const floa
     }
     if (p.emit.ssq) {  // all 64 lanes take part in the shuffles
       float sq = valid ? ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) : 0.f;
-      sq += __shfl_xor(sq, 16);
-      sq += __shfl_xor(sq, 32);
+      sq = sum_xor16_32(sq);
       if (q == 0 && mvalid && ntile * 16 < p.N) p.emit.ssq[(size_t)m * (p.N >> 4) + ntile] = sq;
     }
     STAMP3(4);
