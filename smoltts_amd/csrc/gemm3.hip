@@ -132,7 +132,10 @@ __device__ __forceinline__ bf16x8_t wfrag_bf16(uint4 v) {
 
 __device__ __forceinline__ float silu3(float x) { return x / (1.f + expf(-x)); }
 
-template <int MT, int T, int U, int EPI, bool W8, bool NT = false>  // NT: weight loads with the non-temporal hint (Gemm3Dev.w_nt)
+// FULL (MT == 1): 8 waves with exactly U chunks each and whole groups of T column tiles -- every operand load of the kernel is
+// valid, so the load phase carries no predicates (none of the zero fills, exec masks and branches of the general form: a third of
+// the instructions in front of the last load) and the 8 partial tiles are summed without selects.  Same loads, same sums.
+template <int MT, int T, int U, int EPI, bool W8, bool NT = false, bool FULL = false>  // NT: weight loads with the non-temporal hint (Gemm3Dev.w_nt)
 __global__ __launch_bounds__(512) void gemm3_kernel(const char* w_, const char* x3_, int M_, int N_, int K_, int half_rows_, int nwaves, Gemm3Dev p) {
   // what the first loads need comes as leading scalar arguments (preloaded into SGPRs at wave launch: build.py's
   // -amdgpu-kernarg-preload-count), the rest is read from the kernarg segment behind them (common.h: kernarg_touch)
@@ -171,7 +174,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const char* w_, const char* 
   for (int mt = 0; mt < MT; ++mt) {
     const int mtile = mg * MT + mt;
     xv[mt] = mtile * 16 < p.M && row_on;
-    xb[mt] = p.x3 + (size_t)mtile * nchunks * 3072 + lane * 16;
+    // FULL: a lane whose row belongs to the tile's other half reads the row of its partner lane (r ^ 8: the same lines, nothing
+    // more leaves L2) instead of being masked off; the column of the product it gets is never stored (row_on)
+    const int xlane = FULL ? ((lane & ~8) | (p.half_rows ? (int)(blockIdx.y & 1) << 3 : (lane & 8))) : lane;
+    xb[mt] = p.x3 + (size_t)mtile * nchunks * 3072 + xlane * 16;
   }
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -187,17 +193,17 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const char* w_, const char* 
   auto load_group = [&](int c0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int c = c0 + u * nwaves;
-      const bool cv = c < nchunks;
+      const int c = c0 + u * (FULL ? 8 : nwaves);
+      const bool cv = FULL || c < nchunks;
 #pragma unroll
       for (int t = 0; t < T; ++t)
-        wf[u][t] = (cv && wv[t]) ? load_wfrag<W8, NT>(wb[t] + (size_t)c * WTILE) : make_uint4(0, 0, 0, 0);
+        wf[u][t] = (FULL || (cv && wv[t])) ? load_wfrag<W8, NT>(wb[t] + (size_t)c * WTILE) : make_uint4(0, 0, 0, 0);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int pc = 0; pc < kPieces; ++pc)
-          xf[u][mt][pc] = (cv && xv[mt]) ? *reinterpret_cast<const uint4*>(xb[mt] + (size_t)c * 3072 + pc * 1024)
-                                         : make_uint4(0, 0, 0, 0);
+          xf[u][mt][pc] = (FULL || (cv && xv[mt])) ? *reinterpret_cast<const uint4*>(xb[mt] + (size_t)c * 3072 + pc * 1024)
+                                                   : make_uint4(0, 0, 0, 0);
       }
     }
   };
@@ -254,6 +260,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const char* w_, const char* 
         }
       }
     }
+    if (FULL) break;  // nchunks == 8 U: the one group was all
     c0 += nwaves * U;
     if (c0 < nchunks) load_group(c0);
   }
@@ -302,11 +309,11 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const char* w_, const char* 
     const int t = tf;
     float4 part[8];  // workgroups have at most 8 waves (launch3_epi)
 #pragma unroll
-    for (int w = 0; w < 8; ++w) part[w] = red4[(((w < nwaves ? w : 0) * T + t) * MT + mt) * 64 + lane];
+    for (int w = 0; w < 8; ++w) part[w] = red4[((((FULL || w < nwaves) ? w : 0) * T + t) * MT + mt) * 64 + lane];
     float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
-      const bool on = w < nwaves;
+      const bool on = FULL || w < nwaves;
       v[0] += on ? part[w].x : 0.f;
       v[1] += on ? part[w].y : 0.f;
       v[2] += on ? part[w].z : 0.f;
@@ -1035,9 +1042,13 @@ static int launch3_one(const Gemm3Dev& d, int nwaves, hipStream_t stream) {
   if (nwaves < MT * T) nwaves = MT * T;  // one finishing wave per (column tile, row tile) of the workgroup
   const dim3 grid((ntiles + T - 1) / T, ((d.M + 16 * MT - 1) / (16 * MT)) * (d.half_rows ? 2 : 1));
   const size_t lds = (size_t)nwaves * T * MT * 1024 + (size_t)MT * 16 * sizeof(float);  // partial tiles + the row scales
-  if (MT == 1 && d.w_nt)
-    hipLaunchKernelGGL((gemm3_kernel<MT, T, U, EPI, W8, MT == 1>), grid, dim3(nwaves * 64), lds, stream, d.w, d.x3, d.M, d.N, d.K, d.half_rows, nwaves, d);
-  else hipLaunchKernelGGL((gemm3_kernel<MT, T, U, EPI, W8>), grid, dim3(nwaves * 64), lds, stream, d.w, d.x3, d.M, d.N, d.K, d.half_rows, nwaves, d);
+  const bool full = MT == 1 && nwaves == 8 && d.K / 32 == 8 * U && ntiles % T == 0;  // (MT == 1: every launched row tile starts below M)
+#define ST_G3(NT_, FULL_)                                                                                                          \
+  hipLaunchKernelGGL((gemm3_kernel<MT, T, U, EPI, W8, NT_, FULL_>), grid, dim3(nwaves * 64), lds, stream, d.w, d.x3, d.M, d.N, d.K, \
+                     d.half_rows, nwaves, d)
+  if (MT == 1 && d.w_nt) { if (full) ST_G3(MT == 1, MT == 1); else ST_G3(MT == 1, false); }
+  else { if (full) ST_G3(false, MT == 1); else ST_G3(false, false); }
+#undef ST_G3
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
 }
