@@ -276,7 +276,7 @@ __global__ __launch_bounds__(1024) void attn_split_kernel(const int* row_pos_, c
   float* part = smem;                  // [16 waves][G][64]
   float* stat = smem + 16 * G * 64;    // [16 waves][G][2] (max, sum)
   const int row = blockIdx.x, h = blockIdx.y, prt = NS > 1 ? (int)blockIdx.z : 0;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int kk = lane / LPK, dl = lane % LPK;
   const int pos = p.row_pos[row], slot = p.row_slot[row];
   kernarg_touched(kt);

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const char* w_, const char* 
   p.w = w_; p.x3 = x3_; p.M = M_; p.N = N_; p.K = K_; p.half_rows = half_rows_;
   constexpr int WTILE = W8 ? 512 : 1024, WLANE = W8 ? 8 : 16;  // bytes per weight tile-chunk / per lane
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int r = lane & 15, q = lane >> 4;
   const int ng = blockIdx.x;
   const int mg = p.half_rows ? (blockIdx.y >> 1) : blockIdx.y;
@@ -227,11 +227,21 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const char* w_, const char* 
     for (int j = 0; j < 16; ++j) ssv[j] = 0.f;
     if (p.ssq_in != nullptr && norm_wave) {
       const float* sp = p.ssq_in + (size_t)mc * nt_in;
+      // lane q sums entries q, q + 4, ..: for the usual widths (K = 768: 48 entries, K >= 1024: the first 64) every lane has the
+      // same number of them -- one address and constant offsets, no clamps or selects; anything else takes the general form
+      if (nt_in == 48) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int i = q + 4 * j;
-        const float vld = sp[i < nt_in ? i : nt_in - 1];
-        ssv[j] = i < nt_in ? vld : 0.f;
+        for (int j = 0; j < 12; ++j) ssv[j] = sp[q + 4 * j];
+      } else if (nt_in >= 64) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) ssv[j] = sp[q + 4 * j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int i = q + 4 * j;
+          const float vld = sp[i < nt_in ? i : nt_in - 1];
+          ssv[j] = i < nt_in ? vld : 0.f;
+        }
       }
     }
     {
@@ -790,7 +800,8 @@ __device__ __forceinline__ void awo_compute(const AwoUnit<G, TWO>& u, char* frag
 
 constexpr int AWO_NA = 4, AWO_NB = 8, AWO_U = 3;  // attention waves, GEMM waves, 32-k chunks per GEMM wave (K <= 768)
 
-template <int G, int T, bool TWO, bool W8, bool PICK>  // TWO: more than 4 keys (a second key per lane); PICK: SmolttsPickArgs
+template <int G, int T, bool TWO, bool W8, bool PICK, bool FULL>  // TWO: more than 4 keys (a second key per lane); PICK: SmolttsPickArgs;
+// FULL: 8 K parts of exactly AWO_U chunks and whole groups of T column tiles -- no predicates on the weight stream (see gemm3_kernel)
 __global__ __launch_bounds__(768) void attn_wo_kernel(const char* w_, const float* kc_, const float* vc_, const float* q_or_cand, const float* pk_table_,
                                                       int m_tiles, int N_, int K_, int heads_pos, Gemm3Dev p) {
   // 14 dwords of leading scalar arguments = what the first loads of both kinds of waves need, in SGPRs at wave launch (see gemm3_kernel)
@@ -803,12 +814,12 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(const char* w_, const floa
   constexpr int WTILE = W8 ? 512 : 1024, WLANE = W8 ? 8 : 16;
   constexpr int R = AWO_R, NA = AWO_NA, NB = AWO_NB, U = AWO_U;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int r = lane & 15, q = lane >> 4;
   const int ng = blockIdx.x, row0 = blockIdx.y * R;
   const int nchunks = p.K >> 5;
   // K parts: as many as gemm3_kernel has waves for this K (launch3_fmt), so that the partial sums are the same numbers
-  const int nb = (nchunks + 2) / 3 < 1 ? 1 : ((nchunks + 2) / 3 > NB ? NB : (nchunks + 2) / 3);
+  const int nb = FULL ? NB : ((nchunks + 2) / 3 < 1 ? 1 : ((nchunks + 2) / 3 > NB ? NB : (nchunks + 2) / 3));
   char* frag = reinterpret_cast<char*>(smem);  // [chunk][piece][q][row] x 16 B
   float4* red4 = reinterpret_cast<float4*>(frag + (size_t)nchunks * 3 * 4 * R * 16);  // [GEMM wave][tile][lane]
   STAMP3(0);
@@ -902,7 +913,7 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(const char* w_, const floa
     float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < NB; ++w) {
-      const bool on = w < nb;
+      const bool on = FULL || w < nb;
       v[0] += on ? part[w].x : 0.f;
       v[1] += on ? part[w].y : 0.f;
       v[2] += on ? part[w].z : 0.f;
@@ -940,8 +951,8 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(const char* w_, const floa
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int ntile = ng * T + t;
-      wf[u][t] = (gw < nb && c < nchunks && ntile * 16 < p.N) ? load_wfrag<W8, false>(p.w + ((size_t)ntile * nchunks + c) * WTILE + lane * WLANE)
-                                                   : make_uint4(0, 0, 0, 0);
+      wf[u][t] = (FULL || (gw < nb && c < nchunks && ntile * 16 < p.N)) ? load_wfrag<W8, false>(p.w + ((size_t)ntile * nchunks + c) * WTILE + lane * WLANE)
+                                                             : make_uint4(0, 0, 0, 0);
     }
   }
   kernarg_touched(kt);
@@ -954,7 +965,7 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(const char* w_, const floa
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int c = gw + u * nb;
-    if (gw < nb && c < nchunks) {  // wave-uniform
+    if (FULL || (gw < nb && c < nchunks)) {  // wave-uniform
       const char* fp = frag + ((size_t)((c * 3) * 4 + q) * R + (r & (R - 1))) * 16;
       uint4 xb[3];
 #pragma unroll
@@ -989,9 +1000,12 @@ static int launch_attn_wo_g(const Gemm3Dev& d, hipStream_t stream) {
   const dim3 block((AWO_NA + AWO_NB) * 64);
   ST_REQUIRE(d.M < 65536 && d.pk_tiles < 32768 && d.n_q_heads < 256 && d.cache_len < 256 && d.a_pos < 128, SMOLTTS_E_INVALID,
              "gemm3: attention + wo: sizes out of the packed arguments' range");
+  const bool full = nchunks == AWO_NB * AWO_U && ntiles % T == 0;
   const int m_tiles = d.M | (d.pk_tiles << 16), heads_pos = d.n_q_heads | (d.n_kv_heads << 8) | (d.cache_len << 16) | (d.a_pos << 24);
-#define ST_AWO(TT, TWO_, PK_)                                                                                                   \
-  hipLaunchKernelGGL((attn_wo_kernel<G, TT, TWO_, W8, PK_>), grid, block, lds, stream, d.w, (const float*)d.kc, (const float*)d.vc, \
+#define ST_AWO(TT, TWO_, PK_) \
+  do { if (full) ST_AWO_(TT, TWO_, PK_, true); else ST_AWO_(TT, TWO_, PK_, false); } while (0)
+#define ST_AWO_(TT, TWO_, PK_, FULL_)                                                                                                   \
+  hipLaunchKernelGGL((attn_wo_kernel<G, TT, TWO_, W8, PK_, FULL_>), grid, block, lds, stream, d.w, (const float*)d.kc, (const float*)d.vc, \
                      PK_ ? d.pk_cand : d.aq, d.pk_table, m_tiles, d.N, d.K, heads_pos, d)
   if (d.pk_cand) {
     if (T == 3) { if (two) ST_AWO(3, true, true); else ST_AWO(3, false, true); }
@@ -1001,6 +1015,7 @@ static int launch_attn_wo_g(const Gemm3Dev& d, hipStream_t stream) {
     else { if (two) ST_AWO(1, true, false); else ST_AWO(1, false, false); }
   }
 #undef ST_AWO
+#undef ST_AWO_
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
 }
