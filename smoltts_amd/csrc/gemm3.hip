@@ -958,7 +958,6 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(const char* w_, const floa
   kernarg_touched(kt);
   STAMP3(5);
   __syncthreads();  // the fragments are in LDS
-  const bool row_on = r < R;
   f32x4 acc[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -969,7 +968,7 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(const char* w_, const floa
       const char* fp = frag + ((size_t)((c * 3) * 4 + q) * R + (r & (R - 1))) * 16;
       uint4 xb[3];
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) xb[pc] = row_on ? *reinterpret_cast<const uint4*>(fp + pc * 4 * R * 16) : make_uint4(0, 0, 0, 0);
+      for (int pc = 0; pc < 3; ++pc) xb[pc] = *reinterpret_cast<const uint4*>(fp + pc * 4 * R * 16);  // lanes r >= R: row r mod R again (columns of the product nobody reads)
       bf16x8_t a[T];
 #pragma unroll
       for (int t = 0; t < T; ++t) a[t] = wfrag_bf16<W8>(wf[u][t]);
