@@ -85,9 +85,13 @@ def parse_args(argv=None):
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the first-audio-chunk latency measurement")
     ap.add_argument("--no-mimi", action="store_true", help="diagnostic only: skip the Mimi decode (the result line is then not the metric)")
-    ap.add_argument("--overlap-mimi", action="store_true", help="run the Mimi chunk decode on its own stream behind an event (measured: no gain, the many-workgroup Mimi kernels delay the latency-bound frame graphs)")
-    ap.add_argument("--overlap-wait", default="device", choices=["device", "host"], help="with --overlap-mimi: how the Mimi stream learns that a chunk's codes are ready: a device-side wait_event (parks a blocked barrier packet in the second queue), or the host waits for the event and only then launches (one chunk behind the frame graphs)")
-    ap.add_argument("--mimi-cus", type=int, default=0, help="with --overlap-mimi: restrict the Mimi stream to this many CUs (hipExtStreamCreateWithCUMask)")
+    ap.add_argument("--overlap-mimi", dest="overlap_mimi", action="store_true", default=True,
+                    help="(default) the Mimi chunk decode of chunk i runs on a second stream beside the frame graphs of chunk i + 1, launched by the host once it "
+                         "has seen chunk i's codes (what the serving loop does with its codec passes); measured +3.5 %% at the round-4 kernels "
+                         "(profiles/r04_ab_codec_overlap.txt)")
+    ap.add_argument("--no-overlap-mimi", dest="overlap_mimi", action="store_false", help="the Mimi chunk decode on the frame graphs' own stream, after them (rounds 1-3; what the profiler scripts use)")
+    ap.add_argument("--overlap-wait", default="host", choices=["device", "host"], help="with --overlap-mimi: how the Mimi stream learns that a chunk's codes are ready: the host waits for the event and only then launches (one chunk behind the frame graphs), or a device-side wait_event (parks a blocked barrier packet in the second queue: every dependent launch of the frame graphs slows, -13 %%)")
+    ap.add_argument("--mimi-cus", type=int, default=128, help="with --overlap-mimi: restrict the Mimi stream to this many CUs (hipExtStreamCreateWithCUMask; 0 = no mask): at 128 of 256 the frame graphs always find half the chip free (measured 32.1k against 31.4k unmasked and 31.3k at 64)")
     ap.add_argument("--cu-pattern", default="low", choices=["low", "xcd"], help="which mask bits: the N lowest, or N/32 whole XCDs (bit i -> XCD i mod 8)")
     ap.add_argument("--lm-complement", action="store_true", help="restrict the frame-graph stream to the CUs the Mimi stream does not use")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"], help="weight format of the DualAR Linears (fp8 = e4m3 storage + row scales, dequantised to bf16 in registers: the MFMA operands stay bf16; BASELINE config 5; the model is then the dequantised one)")
@@ -374,10 +378,11 @@ def run_rank(args) -> None:
         else:
             session.prefill(prompts, **kw)
 
-    # The Mimi decode of chunk i only needs the codes of chunk i, so it can run on its own stream behind an
-    # event (--overlap-mimi; off by default: measured no gain).
+    # The Mimi decode of chunk i only needs the codes of chunk i, so it runs on its own stream beside the frame graphs of chunk
+    # i + 1 (--overlap-mimi, the default since round 4; --no-overlap-mimi puts it back on the frame graphs' stream).
     mimi_streams = [torch.cuda.Stream(device=dev, priority=0) for _ in range(S)]
-    if args.overlap_mimi and args.mimi_cus > 0:
+    mimi_cus_used = None
+    if args.overlap_mimi and args.mimi_cus > 0 and not args.no_mimi:
         import ctypes
 
         hip = ctypes.CDLL("libamdhip64.so")
@@ -396,13 +401,20 @@ def run_rank(args) -> None:
             h = ctypes.c_void_p()
             rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), words, m)
             if rc != 0:
-                raise SystemExit(f"hipExtStreamCreateWithCUMask failed: {rc}")
+                raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {rc}")
             return torch.cuda.ExternalStream(h.value, device=dev)
 
-        mimi_streams = [masked_stream(bits, 0) for _ in range(S)]
+        try:
+            mimi_streams = [masked_stream(bits, 0) for _ in range(S)]
+            mimi_cus_used = sum(bits)
+        except (RuntimeError, OSError, AttributeError) as e:  # no masked stream on this runtime: the plain second stream (said on the result line: no "-CU mask")
+            if args.lm_complement:
+                raise SystemExit(str(e))
+            log(f"no CU-masked stream ({e}): the Mimi stream runs unmasked")
         if args.lm_complement:
             streams = [masked_stream([not b for b in bits], -1) for _ in range(S)]
-        log(f"CU masks: Mimi stream on {sum(bits)} of {n_cu} CUs ({args.cu_pattern}); frame graphs on {'the complement' if args.lm_complement else 'all'}")
+        if mimi_cus_used:
+            log(f"CU masks: Mimi stream on {sum(bits)} of {n_cu} CUs ({args.cu_pattern}); frame graphs on {'the complement' if args.lm_complement else 'all'}")
 
     host_wait = args.overlap_mimi and args.overlap_wait == "host" and not args.no_mimi
     behind = [None] * S  # host-wait mode: (event, chunk index) of the chunk whose Mimi decode has not been launched yet
@@ -560,7 +572,7 @@ def run_rank(args) -> None:
                     tot_ns += float(row["Calls"]) * float(row["AverageNs"])
             if calls:
                 rocprof_us = round(tot_ns / calls / 1e3, 3)
-                rocprof_src = f"profiles/{kst.name} (rocprofv3 --kernel-trace --stats of `python3 bench.py --cpu-frames 0 --no-latency`, profiler attached; both instantiations of the kernel, weighted by calls)"
+                rocprof_src = f"profiles/{kst.name} (rocprofv3 --kernel-trace --stats of `python3 bench.py --cpu-frames 0 --no-latency --no-overlap-mimi`, profiler attached; both instantiations of the kernel, weighted by calls)"
         sb, parts = step_bytes(cfg, B, L_mean, CH, args.weights)
         step_ach = sb / (us_per_frame_step * 1e-6) / 1e9
         roofline = {"bound": "hbm", "kernel": "gemm3_kernel<1, 3, 3, 2, false, NT, true> = MT 1, T 3, U 3, SwiGLU epilogue, bf16 weights, predicate-free form (RMSNorm-scaled w1|w3 GEMM; NT = non-temporal weight loads: the 10 slow layers' launches, not the 32 depth launches)",
@@ -773,7 +785,10 @@ def run_rank(args) -> None:
             "config": {"workload": f"{args.model} B={B}/GPU concurrent utterances, chunk {CH} frames/step, "
                                    f"prompts T={min(p.shape[1] for p in mine)}..{max_T}, context {max_T + W * CH}..{max_T + (W + K) * CH}"
                                    + (f", chunked prefill ({pch} columns)" if pch else ""),
-                       "global_batch": B * world, "frames_per_step": B * CH * world, "parallelism": f"dp{world} (utterance-sharded replicas)", "streams_per_gpu": S},
+                       "global_batch": B * world, "frames_per_step": B * CH * world, "parallelism": f"dp{world} (utterance-sharded replicas)", "streams_per_gpu": S,
+                       "codec": "no Mimi decode (--no-mimi)" if args.no_mimi else (
+                           f"chunk i's Mimi decode on a second stream beside chunk i + 1's frame graphs ({args.overlap_wait}-side hand-over"
+                           + (f", {mimi_cus_used}-CU mask" if mimi_cus_used else "") + ")" if args.overlap_mimi else "Mimi decode on the frame graphs' stream, after them")},
             "rtf": round(value / 12.5, 1), "frames_per_s_per_gpu": round(value / world, 1),
             "per_rank_frames_per_s": {"min": round(min(rank_fps), 1), "max": round(max(rank_fps), 1), "ranks": len(rank_fps)},
             "us_per_frame_step": round(us_per_frame_step, 1), "prefill_ms": round(prefill_ms, 2),

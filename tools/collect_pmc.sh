@@ -12,7 +12,7 @@ TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export SMOLTTS_MAX_FRAMES_IN_FLIGHT=2
 export SMOLTTS_FRAMES_PER_GRAPH=1   # one frame per graph launch: the bound above counts frames, and a multi-frame graph is that many at once
-ARGS="bench.py --cpu-frames 0 --no-latency --steps 2 --warmup 1"
+ARGS="bench.py --cpu-frames 0 --no-latency --no-overlap-mimi --steps 2 --warmup 1"   # (counters serialise every kernel: one stream)
 rm -rf /tmp/pmc_fetch /tmp/pmc_write
 timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fetch -o pmc -- python3 $ARGS > gpurun_out/pmc_fetch.log 2>&1 < /dev/null
 timeout -k 10 280 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_write -o pmc -- python3 $ARGS > gpurun_out/pmc_write.log 2>&1 < /dev/null

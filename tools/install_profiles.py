@@ -13,8 +13,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 shutil.copy(G / f"prof_{tag}_kernel_stats.csv", P / f"{tag}_bench_kernel_stats.csv")
 log = (G / f"prof_{tag}.log").read_text(errors="replace").splitlines()
 bench_lines = [ln for ln in log if ln.startswith("[bench") and ("timed" in ln or "in-situ" in ln)] + [ln for ln in log if ln.startswith("{")]
-head = ["# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --cpu-frames 0 --no-latency   (tools/collect_profile.sh "
-        f"{tag}; the default bench command minus the CPU sample and the latency probe)",
+head = ["# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --cpu-frames 0 --no-latency --no-overlap-mimi   (tools/collect_profile.sh "
+        f"{tag}; the default bench command minus the CPU sample and the latency probe, Mimi decode on the frame graphs' stream)",
         "# smoltts_byte_150m, B=32, chunk 32, 9 steps incl. warm-up + the duplicated-launch timing frames; per launch shape; durations in us; MI355X"]
 head += ["# bench (profiler attached): " + ln for ln in bench_lines]
 (P / f"{tag}_bench_kernel_breakdown.txt").write_text("\n".join(head) + "\n" + (G / f"prof_{tag}_breakdown.txt").read_text())
