@@ -113,6 +113,27 @@ def test_attn_wo_against_torch_and_the_two_launches(E, ops, M, Hq, KV, pos):
                       % (torch.equal(again_f, out), torch.equal(again_u, two), msg))
 
 
+@pytest.mark.parametrize("pos", [1, 6])
+def test_attn_wo_predicate_free_form_is_the_same_numbers(E, ops, pos):
+    """attn_wo_kernel<.., FULL> (K = 768: 8 K parts of 3 chunks, 48 column tiles in groups of 3) against the general form of the same
+    kernel, reached with 16 more output columns (49 tiles): the common columns agree bit for bit."""
+    M, Hq, KV = 32, 12, 4
+    g = torch.Generator().manual_seed(4242 + pos)
+    K, N = Hq * 64, Hq * 64
+    q = torch.randn(M, K, generator=g)
+    kc, vc = torch.randn(M, KV, 8, 64, generator=g), torch.randn(M, KV, 8, 64, generator=g)
+    w = bf16r(torch.randn(N + 16, K, generator=g) * 0.04)
+    r = torch.randn(M, N + 16, generator=g)
+    outs = []
+    for n in (N, N + 16):
+        rd = r[:, :n].contiguous().cuda()
+        ops.linear3(None, ops.pack_weight(w[:n]), M, n, K, epilogue=E.EPI_RESID, resid=rd, out=rd, attn_q=q.cuda(), attn_pos=pos,
+                    k_cache=kc.cuda(), v_cache=vc.cuda(), n_q_heads=Hq, n_kv_heads=KV, cache_len=8)
+        outs.append(rd.cpu())
+    assert torch.equal(outs[0], outs[1][:, :N])
+    assert rel_err(outs[0], r[:, :N] + attention_ref(q, kc, vc, pos, Hq) @ w[:N].T) < 2e-5
+
+
 def test_attn_wo_fp8_weights(E, ops):
     M, Hq, KV, pos = 32, 12, 4, 5
     g = torch.Generator().manual_seed(99)

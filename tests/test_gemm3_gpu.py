@@ -191,3 +191,21 @@ def test_attention_short_and_x3_out(E, ops, Hq, Hkv, cache_len, window):
         ref[r] = (torch.softmax(q[r].view(Hq, 1, 64) @ K.transpose(1, 2) / 8.0, dim=-1) @ V).reshape(-1)
     assert rel_err(out, ref) < 2e-5
     assert rel_err(ops.x3_to_float(x3, rows, Hq * 64), out) < 1e-6
+
+
+@pytest.mark.parametrize("M", [5, 16, 32])
+@pytest.mark.parametrize("K,N,extra", [(768, 6144, 16), (768, 2048, 16), (3072, 1536, 16)])
+def test_gemm3_predicate_free_form_is_the_same_numbers(E, ops, M, K, N, extra):
+    """gemm3_kernel<.., FULL> (8 waves x exactly U chunks, whole groups of T column tiles: no predicates on the operand loads)
+    against the general form of the same kernel: the same weights with `extra` more output columns make a tile count that is
+    not a multiple of T, which takes the general form; a column's sum does not depend on its neighbours, so the common columns
+    must agree bit for bit."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    w = bf16r(torch.randn(N + extra, K, generator=g) * 0.05)
+    gamma = 1 + 0.1 * torch.randn(K, generator=g)
+    x3, _, ssq = ops.x3_pack(x.cuda(), gamma.cuda())
+    full = ops.linear3(x3, ops.pack_weight(w[:N]), M, N, K, ssq_in=ssq)
+    general = ops.linear3(x3, ops.pack_weight(w), M, N + extra, K, ssq_in=ssq)
+    assert torch.equal(full, general[:, :N])
+    assert rel_err(full.cpu(), rms_norm_ref(x, gamma, 1e-5) @ w[:N].T) < 2e-5
