@@ -132,13 +132,14 @@ __device__ __forceinline__ bf16x8_t wfrag_bf16(uint4 v) {
 
 __device__ __forceinline__ float silu3(float x) { return x / (1.f + expf(-x)); }
 
-// FULL (MT == 1): 8 waves with exactly U chunks each and whole groups of T column tiles -- every operand load of the kernel is
+// NW != 0 ("FULL", MT == 1): NW = 8 or 6 waves with exactly U chunks each and whole groups of T column tiles -- every operand load of the kernel is
 // valid, so the load phase carries no predicates (none of the zero fills, exec masks and branches of the general form: a third of
 // the instructions in front of the last load) and the 8 partial tiles are summed without selects.  Same loads, same sums.
-template <int MT, int T, int U, int EPI, bool W8, bool NT = false, bool FULL = false>  // NT: weight loads with the non-temporal hint (Gemm3Dev.w_nt)
+template <int MT, int T, int U, int EPI, bool W8, bool NT = false, int NW = 0>  // NT: weight loads with the non-temporal hint (Gemm3Dev.w_nt)
 __global__ __launch_bounds__(512) void gemm3_kernel(const char* w_, const char* x3_, int M_, int N_, int K_, int half_rows_, int nwaves, Gemm3Dev p) {
   // what the first loads need comes as leading scalar arguments (preloaded into SGPRs at wave launch: build.py's
   // -amdgpu-kernarg-preload-count), the rest is read from the kernarg segment behind them (common.h: kernarg_touch)
+  constexpr bool FULL = NW != 0;
   KernargTouch<G3_KERNARG_LINES> kt;
   kernarg_touch(kt);
   p.w = w_; p.x3 = x3_; p.M = M_; p.N = N_; p.K = K_; p.half_rows = half_rows_;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const char* w_, const char* 
   auto load_group = [&](int c0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int c = c0 + u * (FULL ? 8 : nwaves);
+      const int c = c0 + u * (FULL ? NW : nwaves);
       const bool cv = FULL || c < nchunks;
 #pragma unroll
       for (int t = 0; t < T; ++t)
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const char* w_, const char* 
         }
       }
     }
-    if (FULL) break;  // nchunks == 8 U: the one group was all
+    if (FULL) break;  // nchunks == NW U: the one group was all
     c0 += nwaves * U;
     if (c0 < nchunks) load_group(c0);
   }
@@ -319,11 +320,11 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const char* w_, const char* 
     const int t = tf;
     float4 part[8];  // workgroups have at most 8 waves (launch3_epi)
 #pragma unroll
-    for (int w = 0; w < 8; ++w) part[w] = red4[((((FULL || w < nwaves) ? w : 0) * T + t) * MT + mt) * 64 + lane];
+    for (int w = 0; w < 8; ++w) part[w] = red4[((((FULL ? w < NW : w < nwaves) ? w : 0) * T + t) * MT + mt) * 64 + lane];
     float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
-      const bool on = FULL || w < nwaves;
+      const bool on = FULL ? w < NW : w < nwaves;  // (a wave that is not there adds + 0.0: the sum of the NW partial tiles, in order, either way)
       v[0] += on ? part[w].x : 0.f;
       v[1] += on ? part[w].y : 0.f;
       v[2] += on ? part[w].z : 0.f;
@@ -800,8 +801,8 @@ __device__ __forceinline__ void awo_compute(const AwoUnit<G, TWO>& u, char* frag
 
 constexpr int AWO_NA = 4, AWO_NB = 8, AWO_U = 3;  // attention waves, GEMM waves, 32-k chunks per GEMM wave (K <= 768)
 
-template <int G, int T, bool TWO, bool W8, bool PICK, bool FULL>  // TWO: more than 4 keys (a second key per lane); PICK: SmolttsPickArgs;
-// FULL: 8 K parts of exactly AWO_U chunks and whole groups of T column tiles -- no predicates on the weight stream (see gemm3_kernel)
+template <int G, int T, bool TWO, bool W8, bool PICK, int NBF>  // TWO: more than 4 keys (a second key per lane); PICK: SmolttsPickArgs;
+// NBF != 0 ("FULL"): NBF = 8 or 6 K parts of exactly AWO_U chunks and whole groups of T column tiles -- no predicates on the weight stream (see gemm3_kernel)
 __global__ __launch_bounds__(768) void attn_wo_kernel(const char* w_, const float* kc_, const float* vc_, const float* q_or_cand, const float* pk_table_,
                                                       int m_tiles, int N_, int K_, int heads_pos, Gemm3Dev p) {
   // 14 dwords of leading scalar arguments = what the first loads of both kinds of waves need, in SGPRs at wave launch (see gemm3_kernel)
@@ -819,7 +820,8 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(const char* w_, const floa
   const int ng = blockIdx.x, row0 = blockIdx.y * R;
   const int nchunks = p.K >> 5;
   // K parts: as many as gemm3_kernel has waves for this K (launch3_fmt), so that the partial sums are the same numbers
-  const int nb = FULL ? NB : ((nchunks + 2) / 3 < 1 ? 1 : ((nchunks + 2) / 3 > NB ? NB : (nchunks + 2) / 3));
+  constexpr bool FULL = NBF != 0;
+  const int nb = FULL ? NBF : ((nchunks + 2) / 3 < 1 ? 1 : ((nchunks + 2) / 3 > NB ? NB : (nchunks + 2) / 3));
   char* frag = reinterpret_cast<char*>(smem);  // [chunk][piece][q][row] x 16 B
   float4* red4 = reinterpret_cast<float4*>(frag + (size_t)nchunks * 3 * 4 * R * 16);  // [GEMM wave][tile][lane]
   STAMP3(0);
@@ -913,7 +915,7 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(const char* w_, const floa
     float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < NB; ++w) {
-      const bool on = FULL || w < nb;
+      const bool on = w < nb;  // (nb is a constant in the predicate-free form)
       v[0] += on ? part[w].x : 0.f;
       v[1] += on ? part[w].y : 0.f;
       v[2] += on ? part[w].z : 0.f;
@@ -951,7 +953,7 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(const char* w_, const floa
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int ntile = ng * T + t;
-      wf[u][t] = (FULL || (gw < nb && c < nchunks && ntile * 16 < p.N)) ? load_wfrag<W8, false>(p.w + ((size_t)ntile * nchunks + c) * WTILE + lane * WLANE)
+      wf[u][t] = (FULL ? (NBF == NB || gw < nb) : (gw < nb && c < nchunks && ntile * 16 < p.N)) ? load_wfrag<W8, false>(p.w + ((size_t)ntile * nchunks + c) * WTILE + lane * WLANE)
                                                              : make_uint4(0, 0, 0, 0);
     }
   }
@@ -964,7 +966,7 @@ __global__ __launch_bounds__(768) void attn_wo_kernel(const char* w_, const floa
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int c = gw + u * nb;
-    if (FULL || (gw < nb && c < nchunks)) {  // wave-uniform
+    if (FULL ? (NBF == NB || gw < nb) : (gw < nb && c < nchunks)) {  // wave-uniform
       const char* fp = frag + ((size_t)((c * 3) * 4 + q) * R + (r & (R - 1))) * 16;
       uint4 xb[3];
 #pragma unroll
@@ -999,10 +1001,10 @@ static int launch_attn_wo_g(const Gemm3Dev& d, hipStream_t stream) {
   const dim3 block((AWO_NA + AWO_NB) * 64);
   ST_REQUIRE(d.M < 65536 && d.pk_tiles < 32768 && d.n_q_heads < 256 && d.cache_len < 256 && d.a_pos < 128, SMOLTTS_E_INVALID,
              "gemm3: attention + wo: sizes out of the packed arguments' range");
-  const bool full = nchunks == AWO_NB * AWO_U && ntiles % T == 0;
+  const int nb_full = ((nchunks == 8 * AWO_U || nchunks == 6 * AWO_U) && ntiles % T == 0) ? nchunks / AWO_U : 0;
   const int m_tiles = d.M | (d.pk_tiles << 16), heads_pos = d.n_q_heads | (d.n_kv_heads << 8) | (d.cache_len << 16) | (d.a_pos << 24);
 #define ST_AWO(TT, TWO_, PK_) \
-  do { if (full) ST_AWO_(TT, TWO_, PK_, true); else ST_AWO_(TT, TWO_, PK_, false); } while (0)
+  do { if (nb_full == 8) ST_AWO_(TT, TWO_, PK_, 8); else if (nb_full == 6) ST_AWO_(TT, TWO_, PK_, 6); else ST_AWO_(TT, TWO_, PK_, 0); } while (0)
 #define ST_AWO_(TT, TWO_, PK_, FULL_)                                                                                                   \
   hipLaunchKernelGGL((attn_wo_kernel<G, TT, TWO_, W8, PK_, FULL_>), grid, block, lds, stream, d.w, (const float*)d.kc, (const float*)d.vc, \
                      PK_ ? d.pk_cand : d.aq, d.pk_table, m_tiles, d.N, d.K, heads_pos, d)
@@ -1056,12 +1058,15 @@ static int launch3_one(const Gemm3Dev& d, int nwaves, hipStream_t stream) {
   if (nwaves < MT * T) nwaves = MT * T;  // one finishing wave per (column tile, row tile) of the workgroup
   const dim3 grid((ntiles + T - 1) / T, ((d.M + 16 * MT - 1) / (16 * MT)) * (d.half_rows ? 2 : 1));
   const size_t lds = (size_t)nwaves * T * MT * 1024 + (size_t)MT * 16 * sizeof(float);  // partial tiles + the row scales
-  const bool full = MT == 1 && nwaves == 8 && d.K / 32 == 8 * U && ntiles % T == 0;  // (MT == 1: every launched row tile starts below M)
-#define ST_G3(NT_, FULL_)                                                                                                          \
-  hipLaunchKernelGGL((gemm3_kernel<MT, T, U, EPI, W8, NT_, FULL_>), grid, dim3(nwaves * 64), lds, stream, d.w, d.x3, d.M, d.N, d.K, \
+  // the predicate-free form: 8 or 6 waves (K = 768 / 3072 / 1536; K = 576), exactly U chunks each, whole groups of T tiles
+  const int nw_full = (MT == 1 && (nwaves == 8 || nwaves == 6) && d.K / 32 == nwaves * U && ntiles % T == 0) ? nwaves : 0;  // (MT == 1: every launched row tile starts below M)
+#define ST_G3(NT_, NW_)                                                                                                          \
+  hipLaunchKernelGGL((gemm3_kernel<MT, T, U, EPI, W8, NT_, NW_>), grid, dim3(nwaves * 64), lds, stream, d.w, d.x3, d.M, d.N, d.K, \
                      d.half_rows, nwaves, d)
-  if (MT == 1 && d.w_nt) { if (full) ST_G3(MT == 1, MT == 1); else ST_G3(MT == 1, false); }
-  else { if (full) ST_G3(false, MT == 1); else ST_G3(false, false); }
+#define ST_G3N(NT_) do { if (nw_full == 8) ST_G3(NT_, (MT == 1 ? 8 : 0)); else if (nw_full == 6) ST_G3(NT_, (MT == 1 ? 6 : 0)); else ST_G3(NT_, 0); } while (0)
+  if (MT == 1 && d.w_nt) ST_G3N(MT == 1);
+  else ST_G3N(false);
+#undef ST_G3N
 #undef ST_G3
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;

@@ -114,10 +114,11 @@ def test_attn_wo_against_torch_and_the_two_launches(E, ops, M, Hq, KV, pos):
 
 
 @pytest.mark.parametrize("pos", [1, 6])
-def test_attn_wo_predicate_free_form_is_the_same_numbers(E, ops, pos):
-    """attn_wo_kernel<.., FULL> (K = 768: 8 K parts of 3 chunks, 48 column tiles in groups of 3) against the general form of the same
-    kernel, reached with 16 more output columns (49 tiles): the common columns agree bit for bit."""
-    M, Hq, KV = 32, 12, 4
+@pytest.mark.parametrize("Hq,KV", [(12, 4), (9, 3)])
+def test_attn_wo_predicate_free_form_is_the_same_numbers(E, ops, pos, Hq, KV):
+    """attn_wo_kernel<.., NBF> (K = 768 / 576: 8 / 6 K parts of 3 chunks, 48 / 36 column tiles in groups of 3) against the general form
+    of the same kernel, reached with 16 more output columns (49 / 37 tiles): the common columns agree bit for bit."""
+    M = 32
     g = torch.Generator().manual_seed(4242 + pos)
     K, N = Hq * 64, Hq * 64
     q = torch.randn(M, K, generator=g)

@@ -194,9 +194,9 @@ def test_attention_short_and_x3_out(E, ops, Hq, Hkv, cache_len, window):
 
 
 @pytest.mark.parametrize("M", [5, 16, 32])
-@pytest.mark.parametrize("K,N,extra", [(768, 6144, 16), (768, 2048, 16), (3072, 1536, 16)])
+@pytest.mark.parametrize("K,N,extra", [(768, 6144, 16), (768, 2048, 16), (3072, 1536, 16), (576, 3072, 16), (576, 2048, 16), (1536, 576, 16)])
 def test_gemm3_predicate_free_form_is_the_same_numbers(E, ops, M, K, N, extra):
-    """gemm3_kernel<.., FULL> (8 waves x exactly U chunks, whole groups of T column tiles: no predicates on the operand loads)
+    """gemm3_kernel<.., NW> (NW = 8 or 6 waves x exactly U chunks, whole groups of T column tiles: no predicates on the operand loads)
     against the general form of the same kernel: the same weights with `extra` more output columns make a tile count that is
     not a multiple of T, which takes the general form; a column's sum does not depend on its neighbours, so the common columns
     must agree bit for bit."""
