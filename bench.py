@@ -575,7 +575,7 @@ def run_rank(args) -> None:
                 rocprof_src = f"profiles/{kst.name} (rocprofv3 --kernel-trace --stats of `python3 bench.py --cpu-frames 0 --no-latency --no-overlap-mimi`, profiler attached; both instantiations of the kernel, weighted by calls)"
         sb, parts = step_bytes(cfg, B, L_mean, CH, args.weights)
         step_ach = sb / (us_per_frame_step * 1e-6) / 1e9
-        roofline = {"bound": "hbm", "kernel": "gemm3_kernel<1, 3, 3, 2, false, NT, true> = MT 1, T 3, U 3, SwiGLU epilogue, bf16 weights, predicate-free form (RMSNorm-scaled w1|w3 GEMM; NT = non-temporal weight loads: the 10 slow layers' launches, not the 32 depth launches)",
+        roofline = {"bound": "hbm", "kernel": "gemm3_kernel<1, 3, 3, 2, false, NT, 8> = MT 1, T 3, U 3, SwiGLU epilogue, bf16 weights, predicate-free form on 8 waves (RMSNorm-scaled w1|w3 GEMM; NT = non-temporal weight loads: the 10 slow layers' launches, not the 32 depth launches)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "traffic_source": traffic_src,
                     "traffic_kind": "bytes the L2s requested from the fabric (L2 misses; Infinity-Cache hits are counted), not HBM bytes: of this kernel's 42 launches per "
