@@ -176,8 +176,9 @@ __global__ __launch_bounds__(1024) void attn_kernel(AttnDev p) {
   for (int g = 0; g < G; ++g) {
 #pragma unroll
     for (int o = 16; o <= 32; o <<= 1) {
-      const float om = lane_xor_c(mx[g], o, lane), od = lane_xor_c(den[g], o, lane);
-      const float ox = lane_xor_c(acc[g].x, o, lane), oy = lane_xor_c(acc[g].y, o, lane), oz = lane_xor_c(acc[g].z, o, lane), ow = lane_xor_c(acc[g].w, o, lane);
+      // (__shfl_xor here: the VALU exchanges of attn_split_kernel cost this kernel's G = 4 form two registers it does not have -- scratch)
+      const float om = __shfl_xor(mx[g], o), od = __shfl_xor(den[g], o);
+      const float ox = __shfl_xor(acc[g].x, o), oy = __shfl_xor(acc[g].y, o), oz = __shfl_xor(acc[g].z, o), ow = __shfl_xor(acc[g].w, o);
       const float mn = fmaxf(mx[g], om);
       const float sa = mn > -INFINITY ? __expf(mx[g] - mn) : 0.f, sb = mn > -INFINITY ? __expf(om - mn) : 0.f;
       den[g] = den[g] * sa + od * sb;
