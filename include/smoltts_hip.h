@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SMOLTTS_ABI_VERSION 5
+#define SMOLTTS_ABI_VERSION 6
 
 enum {
   SMOLTTS_OK = 0,
@@ -336,6 +336,16 @@ int smoltts_mimi_reset(SmolttsMimiSession* s, void* stream);
 /* Forget the streaming state of the listed slots only (slots_host: host memory): the other slots' streams continue.
  * Every slot keeps its own transformer position, so streams of different utterances can share one session. */
 int smoltts_mimi_reset_slots(SmolttsMimiSession* s, const int32_t* slots_host, int32_t n_slots, void* stream);
+
+/* (ABI 6) Reference-quirk switch, default 0.  SMOLTTS_MIMI_OPT_STATELESS_UPSAMPLE = 1: every decode call up-samples its frames
+ * as if they were the whole utterance (no tap overlap carried in from the previous call), which is what the reference's
+ * decode_step does (mlx_inference/src/smoltts_mlx/codec/mimi.py:73-77,101-104: self.upsample(embeddings) on the call's frames
+ * alone; transformer cache and SEANet state are carried as here).  With one frame per call this reproduces the reference's
+ * SmolTTS.stream (__init__.py:83-95) sample for sample; chunked decode then no longer equals the batch decode -- which is the
+ * reference's defect, kept switchable like the other two torch / MLX disagreements.  Takes effect from the
+ * next decode call; returns SMOLTTS_E_INVALID for an unknown option or a value other than 0 / 1. */
+#define SMOLTTS_MIMI_OPT_STATELESS_UPSAMPLE 1
+int smoltts_mimi_session_set_option(SmolttsMimiSession* s, int32_t option, int32_t value);
 
 /* Decode n_frames new frames for slots [0, batch): codes_dev int32 [batch][codes_stride] where
  * frame f of slot b starts at codes_dev[b*codes_stride + f*frame_stride + code_offset] and holds

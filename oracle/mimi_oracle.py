@@ -28,6 +28,10 @@ Weights are a dict with the Hugging Face ``MimiModel.state_dict()`` key names (t
 Streaming: the reference's ``decode_step`` up-samples each frame statelessly (mimi.py:77), so its
 streaming output differs from its own batch decode.  This oracle defines streaming as the causal
 prefix property instead: chunk f of a stream == samples [1920 f, 1920 (f+1)) of the batch decode.
+``decode(codes, upsample_call_frames=c)`` restates the reference's own streaming instead: the up-sampling
+sees c frames at a time (c = 1: ``SmolTTS.stream``, __init__.py:83-95), everything behind it is causal
+with carried state (transformer cache, ``decoder.step``) and therefore equals the batch computation over
+the concatenated rows.
 """
 from __future__ import annotations
 
@@ -145,10 +149,16 @@ class MimiDecodeOracle:
 
     # -- mimi.py:73-104
     @torch.no_grad()
-    def decode(self, codes: Tensor) -> Tensor:
-        """codes (B, nq, F) int -> pcm (B, 1, 1920 F) float32."""
+    def decode(self, codes: Tensor, upsample_call_frames: Optional[int] = None) -> Tensor:
+        """codes (B, nq, F) int -> pcm (B, 1, 1920 F) float32.  ``upsample_call_frames`` = c: the PCM a stream of
+        ``decode_step`` calls of c frames each yields in the reference (mimi.py:73-77: ``self.upsample`` on the call's frames
+        alone, i.e. taps 2, 3 of a call's last frame never reach the next call's first two rows)."""
         e = self.rvq_decode(codes.long())
-        e = self.upsample(e)
+        if upsample_call_frames:
+            c = int(upsample_call_frames)
+            e = torch.cat([self.upsample(e[:, :, i:i + c]) for i in range(0, e.shape[2], c)], dim=2)
+        else:
+            e = self.upsample(e)
         e = self.transformer(e.transpose(1, 2)).transpose(1, 2)
         return self.seanet(e)
 

@@ -148,10 +148,14 @@ class SmolTTS:
             turns = [self.prompt_encoder.encode_text_turn("system", system_prompt), *turns]
         return np.concatenate(turns, axis=1).astype(np.int32)
 
-    def stream(self, input: str, voice: Optional[str] = "heart", generation_settings=None, overlap: bool = True) -> Iterator["np.ndarray"]:
+    def stream(self, input: str, voice: Optional[str] = "heart", generation_settings=None, overlap: bool = True,
+               reference_upsample: bool = False) -> Iterator["np.ndarray"]:
         """Yields one 1920-sample float32 chunk per generated frame, including the terminating
         <|im_end|> frame (reference stream, __init__.py:83-95, decodes vq_tensor[:, 1:, :] of every
         frame).  The codec carries its streaming state, so the chunks concatenate to the batch decode.
+        ``reference_upsample``: up-sample every frame on its own as the reference's ``decode_step`` does (codec/mimi.py:77:
+        no tap overlap from the previous frame) -- the chunks then equal the reference's own ``stream`` and no longer its batch
+        decode; a quirk kept switchable like ``NumericsMode``'s.
         ``overlap``: the codec step of frame f runs beside frame f + 1 on a second stream (``generate.stream_pcm``); the chunks
         are the same numbers either way."""
         import numpy as np
@@ -167,7 +171,7 @@ class SmolTTS:
         T = int(prompt.shape[1])
         sess = LMSession(self.lm, 1, max_seq=min(self.config.max_seq_len, T + max_new + 2), max_rows=T, max_frames=max_new + 1)
         _apply_sampling(sess, settings)
-        msess = MimiSession(self.codec, max_batch=1, max_chunk_frames=1)
+        msess = MimiSession(self.codec, max_batch=1, max_chunk_frames=1, stateless_upsample=reference_upsample)
         try:
             yield from stream_pcm(sess, msess, prompt, stop_on_eos=True, overlap=overlap)
         finally:

@@ -67,6 +67,7 @@ struct SmolttsMimiSession {
   float final_bias;  // bias of the output conv (read from the arena once, at session creation)
   int* pos_host;     // host mirror (deterministic: += 2 * frames per call for the slots decoded, 0 on reset)
   int parity;
+  int stateless_upsample;  // SMOLTTS_MIMI_OPT_STATELESS_UPSAMPLE: every call up-samples its frames with no carry (mimi.py:77)
 };
 
 namespace {
@@ -137,7 +138,8 @@ __global__ __launch_bounds__(128) void rvq_upsample_kernel(const int* codes, lon
     return e;
   };
   const float4 cur = embed(f);
-  const float4 prev = f > 0 ? embed(f - 1) : *reinterpret_cast<const float4*>(carry_in + (long)b * D + c);
+  // carry_in == nullptr: the call's first frame has no predecessor (the reference's per-call up-sampling, mimi.py:77)
+  const float4 prev = f > 0 ? embed(f - 1) : carry_in ? *reinterpret_cast<const float4*>(carry_in + (long)b * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 w0 = *reinterpret_cast<const float4*>(upw + 0 * D + c), w1 = *reinterpret_cast<const float4*>(upw + 1 * D + c);
   const float4 w2 = *reinterpret_cast<const float4*>(upw + 2 * D + c), w3 = *reinterpret_cast<const float4*>(upw + 3 * D + c);
   float* o = tx + ((long)b * 2 * n_frames + 2 * f) * D + c;
@@ -323,6 +325,14 @@ int smoltts_mimi_reset(SmolttsMimiSession* s, void* stream) {
   return SMOLTTS_OK;
 }
 
+int smoltts_mimi_session_set_option(SmolttsMimiSession* s, int32_t option, int32_t value) {
+  ST_REQUIRE(s, SMOLTTS_E_INVALID, "mimi_session_set_option: null session");
+  ST_REQUIRE(option == SMOLTTS_MIMI_OPT_STATELESS_UPSAMPLE, SMOLTTS_E_INVALID, "mimi_session_set_option: unknown option %d", option);
+  ST_REQUIRE(value == 0 || value == 1, SMOLTTS_E_INVALID, "mimi_session_set_option: value %d (0 or 1)", value);
+  s->stateless_upsample = value;
+  return SMOLTTS_OK;
+}
+
 int smoltts_mimi_reset_slots(SmolttsMimiSession* s, const int32_t* slots_host, int32_t n_slots, void* stream) {
   ST_REQUIRE(s && slots_host && n_slots > 0, SMOLTTS_E_INVALID, "mimi_reset_slots: bad argument");
   hipStream_t st = (hipStream_t)stream;
@@ -383,7 +393,7 @@ static int decode_chunk_impl(SmolttsMimiSession* s, const int32_t* codes_dev, in
   // 1. RVQ gather (+ folded output_proj) and depthwise upsample -> transformer rows tx[b][2F][512]
   hipLaunchKernelGGL(rvq_upsample_kernel, dim3(F, batch), dim3(128), 0, st, codes_dev, (long)codes_stride, frame_stride, code_offset,
                      c.num_codebooks, F, (const float*)(A + m->w.rvq_table), (const float*)(A + m->w.upsample_w),
-                     s->carry[s->parity], s->carry[s->parity ^ 1], s->tx);
+                     s->stateless_upsample ? (const float*)nullptr : (const float*)s->carry[s->parity], s->carry[s->parity ^ 1], s->tx);
   ST_CHECK_HIP(hipGetLastError());
   ST_TRY(launch_mimi_rows(R, Tt, 0, s->row_pos, s->row_slot, st, s->pos_dev));
 

@@ -107,7 +107,7 @@ _EXPORTS = [
     "smoltts_session_measure_duplicate", "smoltts_session_margin_at", "smoltts_session_drop_graph", "smoltts_session_set_frames_per_graph", "smoltts_engine_fast_qkv_bytes", "smoltts_engine_build_fast_qkv", "smoltts_session_set_option", "smoltts_gemm3_attn_fusable", "smoltts_lm_park_slots", "smoltts_lm_prefill_side", "smoltts_lm_start_slots", "smoltts_session_kv_cache", "smoltts_k_attention_split", "smoltts_k_attention_rows3",
     "smoltts_session_slab_bytes_kv", "smoltts_session_create_kv", "smoltts_k_attention_kv", "smoltts_session_set_sampling", "smoltts_k_sample",
     "smoltts_lm_prefill_chunk", "smoltts_lm_prefill_deferred", "smoltts_mimi_reset_slots", "smoltts_mimi_encoder_create", "smoltts_mimi_encoder_destroy", "smoltts_mimi_encode_frames",
-    "smoltts_mimi_encode_workspace_bytes", "smoltts_mimi_encode",
+    "smoltts_mimi_encode_workspace_bytes", "smoltts_mimi_encode", "smoltts_mimi_session_set_option",
 ]
 
 
@@ -194,7 +194,8 @@ def load_library(path: Optional[Path] = None):
     if hasattr(lib, "smoltts_profile_begin"):  # diagnostic builds only (-DSMOLTTS_DEBUG_HOOKS)
         lib.smoltts_profile_begin.argtypes = [C.c_int32] * 4
         lib.smoltts_profile_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
-    if lib.smoltts_abi_version() != 5:
+    lib.smoltts_mimi_session_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    if lib.smoltts_abi_version() != 6:
         raise SmolttsError("libsmoltts_hip.so ABI version mismatch")
     if path is None:
         _lib = lib
@@ -703,8 +704,11 @@ class MimiSession:
     """Streaming Mimi decode state for ``max_batch`` slots; ``decode`` consumes frames chunk-wise."""
 
     SAMPLES_PER_FRAME = 1920
+    OPT_STATELESS_UPSAMPLE = 1  # SMOLTTS_MIMI_OPT_STATELESS_UPSAMPLE
 
-    def __init__(self, engine: MimiEngine, max_batch: int, max_chunk_frames: int = 8):
+    def __init__(self, engine: MimiEngine, max_batch: int, max_chunk_frames: int = 8, stateless_upsample: bool = False):
+        """``stateless_upsample``: every decode call up-samples its frames with no tap overlap carried in from the call before --
+        the reference's ``decode_step`` (codec/mimi.py:73-77,101-104); off, chunked decode == batch decode."""
         self.engine, self.lib = engine, engine.lib
         self.B, self.chunk = max_batch, max_chunk_frames
         need = self.lib.smoltts_mimi_slab_bytes(engine.handle, max_batch, max_chunk_frames)
@@ -715,6 +719,12 @@ class MimiSession:
         check(self.lib.smoltts_mimi_session_create(engine.handle, dptr(self.slab), need, max_batch, max_chunk_frames, C.byref(h)),
               "smoltts_mimi_session_create")
         self.handle = h
+        if stateless_upsample:
+            self.set_stateless_upsample(True)
+
+    def set_stateless_upsample(self, on: bool) -> None:
+        check(self.lib.smoltts_mimi_session_set_option(self.handle, self.OPT_STATELESS_UPSAMPLE, int(bool(on))),
+              "smoltts_mimi_session_set_option")
 
     def reset(self) -> None:
         check(self.lib.smoltts_mimi_reset(self.handle, current_stream_ptr()), "smoltts_mimi_reset")

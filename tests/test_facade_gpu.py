@@ -59,6 +59,21 @@ def test_stream_chunks_concatenate_to_batch_decode(setup):
     assert _rms(np.concatenate(chunks) - ref) <= 1e-4
 
 
+def test_stream_with_the_reference_upsample(setup):
+    """``stream(..., reference_upsample=True)``: the chunks of the reference's own ``stream`` (every frame up-sampled alone,
+    codec/mimi.py:77) -- the oracle's per-call form at one frame per call."""
+    from smoltts_amd.config import GenerationSettings
+
+    cfg, state, mst, tts, orc, morc, _ = setup
+    gs = GenerationSettings.greedy(max_new_tokens=5)
+    chunks = list(tts.stream("streaming", "heart", generation_settings=gs, reference_upsample=True))
+    prompt = tts._get_prompt("streaming", "heart")
+    grid = orc.generate([torch.from_numpy(prompt)], max_frames=6, stop_on_eos=True)[0].as_tensor()
+    ref = morc.decode(grid[1:][None], upsample_call_frames=1)[0, 0].numpy()
+    assert len(chunks) == 6 and _rms(np.concatenate(chunks) - ref) <= 1e-4
+    assert _rms(np.concatenate(chunks) - morc.decode(grid[1:][None])[0, 0].numpy()) > 1e-3
+
+
 def test_overlapped_stream_yields_the_same_chunks(setup):
     """``stream`` runs the codec step of frame f beside frame f + 1 (generate.stream_pcm): same chunks, bit for bit, as the
     one-stream loop, also when the utterance ends by <|im_end|> or by its frame budget."""

@@ -152,7 +152,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} is declared in include/smoltts_hip.h but not exported"
     for name in engine.exported_symbols():
         assert name in declared, f"{name} is bound by engine.py but not declared in the header"
-    assert lib.smoltts_abi_version() == 5
+    assert lib.smoltts_abi_version() == 6
     assert isinstance(lib.smoltts_last_error(), bytes)
 
 

@@ -45,6 +45,31 @@ def test_decode_matches_oracle(mimi, B, F, chunk):
     sess.close()
 
 
+@pytest.mark.parametrize("B,F,chunk", [(1, 6, 1), (2, 7, 2), (3, 9, 4)])
+def test_stateless_upsample_matches_the_reference_stream(mimi, B, F, chunk):
+    """SMOLTTS_MIMI_OPT_STATELESS_UPSAMPLE: every call up-samples its frames alone, as the reference's decode_step does
+    (codec/mimi.py:73-77) -- parity with the oracle's ``upsample_call_frames``; switched off again, the same session decodes the
+    batch result; the option rejects what it does not know."""
+    from smoltts_amd.engine import MimiSession, SmolttsError, check
+
+    st, eng, orc = mimi
+    codes = torch.randint(0, 2048, (B, 8, F), generator=torch.Generator().manual_seed(B * 10 + F))
+    dev_codes = codes.permute(0, 2, 1).contiguous().int().cuda()
+    ref_stream = orc.decode(codes, upsample_call_frames=chunk)[:, 0].numpy()
+    ref_batch = orc.decode(codes)[:, 0].numpy()
+    assert _rms(ref_stream - ref_batch) > 1e-3  # the two really are different signals
+    sess = MimiSession(eng, max_batch=B, max_chunk_frames=chunk, stateless_upsample=True)
+    pcm = sess.decode(dev_codes).cpu().numpy()
+    err = _rms(pcm - ref_stream)
+    print(f"B={B} F={F} calls of {chunk}: rms err vs the reference stream {err:.3e}, vs the batch decode {_rms(pcm - ref_batch):.3e}")
+    assert err <= RMS_TOL
+    sess.set_stateless_upsample(False)
+    assert _rms(sess.decode(dev_codes).cpu().numpy() - ref_batch) <= RMS_TOL
+    with pytest.raises(SmolttsError):
+        check(sess.lib.smoltts_mimi_session_set_option(sess.handle, 99, 1), "smoltts_mimi_session_set_option")
+    sess.close()
+
+
 def test_codes_embedded_in_lm_rows(mimi):
     """The LM session stores columns as [slow id, c0..c7]; Mimi reads them in place (code_offset=1)."""
     from smoltts_amd.engine import MimiSession

@@ -101,3 +101,37 @@ def test_mimi_oracle_is_causal():
     codes = torch.randint(0, 2048, (1, 8, 7), generator=torch.Generator().manual_seed(0))
     full, prefix = orc.decode(codes), orc.decode(codes[:, :, :3])
     assert float((full[..., : 3 * 1920] - prefix).abs().max()) < 1e-5
+
+
+def test_mimi_oracle_per_call_upsample_is_the_reference_stream():
+    """``decode(codes, upsample_call_frames=c)``: what a stream of ``decode_step`` calls of c frames yields in the reference
+    (codec/mimi.py:73-77: ``self.upsample`` sees the call's frames only; conv.py:273-282: full transposed conv, k - stride = 2 rows
+    trimmed on the right).  Checked against that definition written out per frame, and against the properties that follow from it."""
+    import torch.nn.functional as F
+
+    from oracle.mimi_oracle import MimiDecodeOracle
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+
+    st = synthetic_mimi_state(seed=2)
+    orc = MimiDecodeOracle(st)
+    codes = torch.randint(0, 2048, (2, 8, 6), generator=torch.Generator().manual_seed(5))
+    batch = orc.decode(codes)
+    # one call over the whole utterance (or more): the batch decode, bit for bit
+    assert torch.equal(orc.decode(codes, upsample_call_frames=6), batch) and torch.equal(orc.decode(codes, upsample_call_frames=64), batch)
+    # c = 1, from the definition: rows (2f, 2f + 1) = e[f] * w[:, 0], e[f] * w[:, 1]; taps 2, 3 fall into the trimmed rows
+    e = orc.rvq_decode(codes.long())  # B, 512, F
+    w = st["upsample.conv.weight"]  # 512, 1, 4
+    rows = []
+    for f in range(6):
+        y = F.conv_transpose1d(e[:, :, f:f + 1], w, None, stride=2, groups=512)  # B, 512, 4
+        rows.append(y[:, :, :2])
+        assert torch.allclose(y[:, :, 0], e[:, :, f] * w[:, 0, 0]) and torch.allclose(y[:, :, 1], e[:, :, f] * w[:, 0, 1])
+    up1 = torch.cat(rows, dim=2)
+    ref1 = orc.seanet(orc.transformer(up1.transpose(1, 2)).transpose(1, 2))
+    one = orc.decode(codes, upsample_call_frames=1)
+    assert torch.allclose(one, ref1, atol=1e-6)
+    # the first call has nothing to lose; later calls differ from the batch decode (the reference's defect)
+    two = orc.decode(codes, upsample_call_frames=2)
+    assert float((two[..., : 2 * 1920] - batch[..., : 2 * 1920]).abs().max()) < 1e-5
+    assert float((two[..., 2 * 1920:] - batch[..., 2 * 1920:]).abs().max()) > 1e-3
+    assert float((one[..., 1920:] - batch[..., 1920:]).abs().max()) > 1e-3
