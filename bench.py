@@ -96,6 +96,7 @@ def parse_args(argv=None):
     ap.add_argument("--lm-complement", action="store_true", help="restrict the frame-graph stream to the CUs the Mimi stream does not use")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"], help="weight format of the DualAR Linears (fp8 = e4m3 storage + row scales, dequantised to bf16 in registers: the MFMA operands stay bf16; BASELINE config 5; the model is then the dequantised one)")
     ap.add_argument("--fp8-prefill", action="store_true", help="with --weights fp8: prompt prefills of >= 256 rows on the fp8 x fp8 MFMA (SMOLTTS_OPT_FP8_PREFILL: BASELINE configs[4]'s 'fp8 MFMA prefill'); the prompt KV rows are then approximate, ids are not comparable with the oracle: the oracle legs are skipped and the line says so")
+    ap.add_argument("--codec-products", type=int, default=6, choices=[3, 6], help="bf16x3 products per operand pair in the codec's matrix-core kernels (SMOLTTS_MIMI_OPT_PRODUCTS): 6 = fp32-grade (default, PCM RMS ~1e-7 vs the fp32 oracle), 3 = the 2^-16-grade form (chunks 23 %% faster, PCM RMS ~7e-7; the bar is 1e-4) -- the line's dtype says which")
     ap.add_argument("--streams", type=int, default=1, help="independent decode streams per GPU (slots are split evenly)")
     ap.add_argument("--kv", default="fp32", choices=["fp32", "bf16"], help="KV-cache storage of the slow transformer (bf16: K/V rounded once when written; the oracle rounds identically)")
     ap.add_argument("--rehearse-launcher", action="store_true", help="no GPU, no compute: start the ranks, run the distributed plumbing of the bench (rendezvous, ranks_seen all-reduce, weight broadcast, sharding, barriers, timing reductions) over gloo and print the line")
@@ -368,7 +369,7 @@ def run_rank(args) -> None:
     sessions = [LMSession(eng, max_batch=Bs, max_seq=max_T + total_frames + 8,
                           max_rows=sum(min(p.shape[1], pch) if pch else p.shape[1] for p in g), max_frames=total_frames, kv_dtype=args.kv)
                 for g in groups]
-    msessions = [MimiSession(meng, max_batch=Bs, max_chunk_frames=CH) for _ in range(S)]
+    msessions = [MimiSession(meng, max_batch=Bs, max_chunk_frames=CH, products=args.codec_products) for _ in range(S)]
     pcms = [torch.zeros(Bs, total_frames * 1920, dtype=torch.float32, device=dev) for _ in range(S)]
     sess = sessions[0]
 
@@ -780,7 +781,7 @@ def run_rank(args) -> None:
                       + (" [fp8 MFMA prefill: prompt KV rows approximate, ids NOT comparable with the reference greedy decode]" if args.fp8_prefill else ""),
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "ranks_seen": seen, "steps": K, "warmup": W,
             "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": f"{wdesc}, fp32 activations/accumulate, {args.kv} KV cache (LM); fp32 (Mimi)",
+            "vs_baseline": None, "dtype": f"{wdesc}, fp32 activations/accumulate, {args.kv} KV cache (LM); " + ("fp32 (Mimi)" if args.codec_products == 6 else "Mimi on hi + mid bf16 operand pieces, three exact products per pair, fp32 accumulate (--codec-products 3: 2^-16-grade, not the default)"),
             "data": "synthetic (seeded random weights at the real shapes, synthetic ChatML prompts)",
             "config": {"workload": f"{args.model} B={B}/GPU concurrent utterances, chunk {CH} frames/step, "
                                    f"prompts T={min(p.shape[1] for p in mine)}..{max_T}, context {max_T + W * CH}..{max_T + (W + K) * CH}"

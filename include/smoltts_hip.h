@@ -343,8 +343,16 @@ int smoltts_mimi_reset_slots(SmolttsMimiSession* s, const int32_t* slots_host, i
  * alone; transformer cache and SEANet state are carried as here).  With one frame per call this reproduces the reference's
  * SmolTTS.stream (__init__.py:83-95) sample for sample; chunked decode then no longer equals the batch decode -- which is the
  * reference's defect, kept switchable like the other two torch / MLX disagreements.  Takes effect from the
- * next decode call; returns SMOLTTS_E_INVALID for an unknown option or a value other than 0 / 1. */
+ * next decode call; returns SMOLTTS_E_INVALID for an unknown option or a value other than 0 / 1.
+ *
+ * SMOLTTS_MIMI_OPT_PRODUCTS = 3 | 6 (default 6): how many of the bf16 x bf16 products of the split operands the codec's matrix-core
+ * kernels form (every Linear, conv, ConvTranspose and the chunk attention of many-row calls, and the fused SEANet stages at any
+ * chunk size; the skinny GEMMs of few-row calls are fp32-MFMA kernels and do not change).  6: every product of weight >= 2^-16 -- fp32-grade, PCM RMS ~1e-7 against the fp32 oracle.  3: the products of
+ * weight >= 2^-8 only -- half the matrix-core work, the lo pieces are never loaded: a 1024-frame chunk decodes 23 % faster at a PCM
+ * RMS error of 7e-7 against the fp32 oracle (signal RMS 0.2-0.4; the contract's bar is 1e-4).  The reference's own codec runs fp32
+ * (codec/mimi.py:107,147: format "fp32" unless "bf16" is asked for), hence the default. */
 #define SMOLTTS_MIMI_OPT_STATELESS_UPSAMPLE 1
+#define SMOLTTS_MIMI_OPT_PRODUCTS 2
 int smoltts_mimi_session_set_option(SmolttsMimiSession* s, int32_t option, int32_t value);
 
 /* Decode n_frames new frames for slots [0, batch): codes_dev int32 [batch][codes_stride] where
@@ -454,6 +462,8 @@ typedef struct SmolttsGemmArgs {
   void* k_cache3_dev;         /* EPI_QKV_ROPE, optional (both or neither): the same K / V rows also as bf16x3 PIECE caches, the operands */
   void* v_cache3_dev;         /* of smoltts_k_attention_rows3 (layouts there); SMOLTTS_KV3_BYTES(slots, n_kv, cache_len) bytes each, */
                               /* zero-filled once by the owner (unwritten positions are multiplied by zero weights: they must be finite) */
+  int32_t b3_products;        /* (ABI 6) calls that run on bf16x3 pieces (w3_dev): 3 = three MFMA products per operand pair (hi*hi, mid*hi, */
+                              /* hi*mid: 2^-16-grade results, lo pieces never loaded), anything else = six (fp32-grade, the default) */
 } SmolttsGemmArgs;
 
 /* bytes of one bf16x3 piece cache: per (slot, kv head) 6 bytes per value over cache_len rounded up to whole 32-position blocks */

@@ -729,7 +729,7 @@ struct Rows3Dev {
   int n_heads, cache_len, window, rows_per_slot, n_units, members;  // units = (slot group, head); members = row groups per slot
 };
 
-template <int RT>
+template <int RT, int NP>
 __global__ __launch_bounds__(256) void attn_rows3_kernel(Rows3Dev p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int r = lane & 15, q = lane >> 4;
@@ -815,7 +815,7 @@ __global__ __launch_bounds__(256) void attn_rows3_kernel(Rows3Dev p) {
           uint4 qf[3];
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc) qf[pc] = qs[((rt * 2 + c) * 3 + pc) * 64 + lane + fresh];
-          a = mfma_b3(kf[tl][c], qf, a);
+          a = mfma_b3<NP>(kf[tl][c], qf, a);
         }
         sc[rt][tl] = a;
       }
@@ -844,7 +844,7 @@ __global__ __launch_bounds__(256) void attn_rows3_kernel(Rows3Dev p) {
       for (int t = 0; t < 4; ++t) {
         f32x4 a = o[rt][t];
         a[0] *= rs; a[1] *= rs; a[2] *= rs; a[3] *= rs;
-        o[rt][t] = mfma_b3(vf[t], pf, a);
+        o[rt][t] = mfma_b3<NP>(vf[t], pf, a);
       }
     }
     if (pb + 4 <= b_hi) { R3_LOAD_V(pb + 4) }
@@ -1066,7 +1066,7 @@ int launch_attention(const float* q, const void* kc, const void* vc, const int32
 }
 
 int launch_attention_rows3(const float* q, const void* kc3, const void* vc3, const int32_t* row_pos, const int32_t* row_slot, int n_rows,
-                           int rows_per_slot, int n_heads, int cache_len, int window, float* out, hipStream_t stream) {
+                           int rows_per_slot, int n_heads, int cache_len, int window, float* out, hipStream_t stream, int b3_products) {
   ST_REQUIRE(q && kc3 && vc3 && row_pos && row_slot && out, SMOLTTS_E_INVALID, "attention_rows3: null pointer");
   ST_REQUIRE(n_rows > 0 && n_heads > 0 && cache_len > 0 && rows_per_slot > 0 && rows_per_slot % 32 == 0 && n_rows % rows_per_slot == 0,
              SMOLTTS_E_INVALID, "attention_rows3: bad shape rows=%d rows_per_slot=%d heads=%d cache_len=%d", n_rows, rows_per_slot, n_heads, cache_len);
@@ -1074,7 +1074,8 @@ int launch_attention_rows3(const float* q, const void* kc3, const void* vc3, con
              (n_rows / rows_per_slot) * n_heads, rows_per_slot / 32};
   const long blocks = (long)((d.n_units + 7) / 8) * 8 * d.members;
   ST_REQUIRE(blocks < (1L << 30), SMOLTTS_E_INVALID, "attention_rows3: grid too large");
-  hipLaunchKernelGGL((attn_rows3_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, stream, d);
+  if (b3_products == 3) hipLaunchKernelGGL((attn_rows3_kernel<2, 3>), dim3((unsigned)blocks), dim3(256), 0, stream, d);
+  else hipLaunchKernelGGL((attn_rows3_kernel<2, 6>), dim3((unsigned)blocks), dim3(256), 0, stream, d);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
 }

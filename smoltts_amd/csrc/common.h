@@ -192,7 +192,8 @@ int launch_attention(const float* q, const void* kc, const void* vc, const int32
                      int kv_format = SMOLTTS_KV_F32, int iota_pos = -1,  // iota_pos >= 0 (caches <= 16): row r = slot r at that position
                      float* split_part = nullptr, int32_t* split_ticket = nullptr);
 int launch_attention_rows3(const float* q, const void* kc3, const void* vc3, const int32_t* row_pos, const int32_t* row_slot, int n_rows,
-                           int rows_per_slot, int n_heads, int cache_len, int window, float* out, hipStream_t stream);  // attention.hip  // key-split decode attention (attention.hip)
+                           int rows_per_slot, int n_heads, int cache_len, int window, float* out, hipStream_t stream,
+                           int b3_products = 6);  // attention.hip; b3_products = 3: three products per operand pair (gemm_dev.h, mfma_b3)  // key-split decode attention (attention.hip)
 // scratch of the key-split attention: records for this many (row, kv head) pairs x 2 parts x (4 heads x 64 + 8) floats, one ticket per pair
 constexpr int ATT_SPLIT_MAX_PAIRS = 128;
 constexpr size_t ATT_SPLIT_PART_FLOATS = (size_t)ATT_SPLIT_MAX_PAIRS * 2 * (4 * 64 + 8);

@@ -40,7 +40,7 @@ __device__ unsigned long long g_ks_stamps[8 * 8];  // [NTW, 3 = NTW 4 in 3 colum
 #define KS_STAMP(I)
 #endif
 
-template <int NTW, int EPI>
+template <int NTW, int EPI, int NP>
 __global__ __launch_bounds__(512) void conv_ks_kernel(GemmDev p, int tiles_per_slot, int nparts) {
   constexpr int MT = 4;
   extern __shared__ __attribute__((aligned(16))) uint4 xp[];  // two slice buffers
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(GemmDev p, int tiles_per_s
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                                 \
       uint4 xf[3];                                                                                                      \
       _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) xf[pc] = xs[(pc * KS_GS + (XC) * 4 + q) * KS_RA + mt * 16 + r + tap]; \
-      _Pragma("unroll") for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma_b3(wq[BUF][t], xf, acc[mt][t]);                \
+      _Pragma("unroll") for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma_b3<NP>(wq[BUF][t], xf, acc[mt][t]);                \
     }                                                                                                                   \
   }
   for (int s = 0; s < nslices; ++s) {
@@ -173,18 +173,23 @@ __global__ __launch_bounds__(512) void conv_ks_kernel(GemmDev p, int tiles_per_s
 #endif
 }
 
-template <int NTW>
-int launch_ks(const GemmDev& g, int tiles_per_slot, int nparts, hipStream_t stream) {
+template <int NTW, int NP>
+int launch_ks_np(const GemmDev& g, int tiles_per_slot, int nparts, hipStream_t stream) {
   static PerDevice attr;
   const int dev = PerDevice::current();
   if (!attr.done(dev)) {  // > 64 KB of dynamic LDS must be requested per kernel and device
-    ST_CHECK_HIP(hipFuncSetAttribute((const void*)conv_ks_kernel<NTW, SMOLTTS_EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KS_LDS_BYTES));
+    ST_CHECK_HIP(hipFuncSetAttribute((const void*)conv_ks_kernel<NTW, SMOLTTS_EPI_STORE, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KS_LDS_BYTES));
     attr.mark_done(dev);
   }
   const long blocks = (long)tiles_per_slot * (g.M / g.rows_per_batch) * nparts;
-  hipLaunchKernelGGL((conv_ks_kernel<NTW, SMOLTTS_EPI_STORE>), dim3((unsigned)blocks), dim3(512), KS_LDS_BYTES, stream, g, tiles_per_slot, nparts);
+  hipLaunchKernelGGL((conv_ks_kernel<NTW, SMOLTTS_EPI_STORE, NP>), dim3((unsigned)blocks), dim3(512), KS_LDS_BYTES, stream, g, tiles_per_slot, nparts);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
+}
+
+template <int NTW>
+int launch_ks(const GemmDev& g, int tiles_per_slot, int nparts, hipStream_t stream) {
+  return g.b3_products == 3 ? launch_ks_np<NTW, 3>(g, tiles_per_slot, nparts, stream) : launch_ks_np<NTW, 6>(g, tiles_per_slot, nparts, stream);
 }
 
 // column tiles per wave: the largest of 4 / 2 / 1 that still gives the chip a workgroup per CU

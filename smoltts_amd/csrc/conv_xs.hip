@@ -37,7 +37,7 @@ __device__ unsigned long long g_xs_stamps[8 * 8];  // [epilogue][phase 0..5, 6 =
 #endif
 
 // MT 16-row tiles of output rows per workgroup, NTW column tiles per wave, RA LDS rows per plane, EPI the epilogue (gemm_dev.h)
-template <int NTW, int MT, int RA, int EPI>
+template <int NTW, int MT, int RA, int EPI, int NP>
 __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
   constexpr int XS_S = 16 * MT, XS_MT = MT, XS_RA = RA;
   extern __shared__ __attribute__((aligned(16))) uint4 xp[];  // [piece][C_in / 8 groups = (chunk, q)][XS_RA rows]
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
     _Pragma("unroll") for (int mt = 0; mt < XS_MT; ++mt) {                                                              \
       uint4 xf[3];                                                                                                      \
       _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) xf[pc] = xp[(pc * G + xc * 4 + q) * XS_RA + mt * 16 + r + tap];  \
-      _Pragma("unroll") for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma_b3(wq[BUF][t], xf, acc[mt][t]);                \
+      _Pragma("unroll") for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma_b3<NP>(wq[BUF][t], xf, acc[mt][t]);                \
     }                                                                                                                   \
     if (++xc == p.cpt) { xc = 0; ++tap; }                                                                               \
   }
@@ -238,21 +238,26 @@ __global__ __launch_bounds__(512) void conv_xs_kernel(GemmDev p) {
 #endif
 }
 
-template <int NTW, int MT, int RA, int EPI>
-int launch_xs(const GemmDev& g, int nsplit, hipStream_t stream) {
+template <int NTW, int MT, int RA, int EPI, int NP>
+int launch_xs_np(const GemmDev& g, int nsplit, hipStream_t stream) {
   const size_t lds = (size_t)3 * (g.cpt * 4) * RA * 16 + (g.ln_w ? (32 * 64 + 64) * sizeof(float) : 0);
   static PerDevice attr;  // value[d] = the largest size requested on device d so far
   const int dev = PerDevice::current();
   if (!attr.done(dev) || (int)lds > attr.value[dev]) {  // > 64 KB of dynamic LDS must be requested per kernel and device
-    ST_CHECK_HIP(hipFuncSetAttribute((const void*)conv_xs_kernel<NTW, MT, RA, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ST_CHECK_HIP(hipFuncSetAttribute((const void*)conv_xs_kernel<NTW, MT, RA, EPI, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if ((int)lds > attr.value[dev]) attr.value[dev] = (int)lds;
     attr.mark_done(dev);
   }
   const int T = g.rows_per_batch > 0 ? g.rows_per_batch : g.M;
   const dim3 grid((T + 16 * MT - 1) / (16 * MT), g.M / T, nsplit);
-  hipLaunchKernelGGL((conv_xs_kernel<NTW, MT, RA, EPI>), grid, dim3(512), lds, stream, g);
+  hipLaunchKernelGGL((conv_xs_kernel<NTW, MT, RA, EPI, NP>), grid, dim3(512), lds, stream, g);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
+}
+
+template <int NTW, int MT, int RA, int EPI>
+int launch_xs(const GemmDev& g, int nsplit, hipStream_t stream) {
+  return g.b3_products == 3 ? launch_xs_np<NTW, MT, RA, EPI, 3>(g, nsplit, stream) : launch_xs_np<NTW, MT, RA, EPI, 6>(g, nsplit, stream);
 }
 
 // fc2 of the decoder transformer (K = 2048, N = 512, layer scale + residual): K in four parts of 512, one workgroup each

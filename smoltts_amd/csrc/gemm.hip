@@ -504,7 +504,7 @@ static int launch_gemm_impl(const SmolttsGemmArgs& a, hipStream_t stream) {
   d.rows_per_batch = a.rows_per_batch; d.M = a.M; d.N = a.N; d.K = a.K; d.gamma = a.gamma_dev; d.eps = a.eps;
   d.bias = a.bias_dev; d.scale = a.scale_dev; d.resid = a.resid_dev; d.out = a.out_dev; d.ldo = a.ldo;
   d.raw_out = a.raw_out_dev; d.raw_bstride = a.raw_bstride; d.elu_out = a.elu_out; d.pro_elu = a.prologue == SMOLTTS_PRO_ELU;
-  d.ln_w = nullptr; d.ln_b = nullptr;
+  d.ln_w = nullptr; d.ln_b = nullptr; d.b3_products = a.b3_products;
   d.o_bstride = a.o_bstride; d.ldr = a.ldr ? a.ldr : a.ldo; d.r_bstride = a.ldr ? a.r_bstride : a.o_bstride;
   d.rope = a.rope_dev; d.row_pos = a.row_pos_dev; d.row_slot = a.row_slot_dev;
   d.kc = a.k_cache_dev; d.vc = a.v_cache_dev; d.kc3 = (char*)a.k_cache3_dev; d.vc3 = (char*)a.v_cache3_dev; d.n_q_heads = a.n_q_heads; d.n_kv_heads = a.n_kv_heads;

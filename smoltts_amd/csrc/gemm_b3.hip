@@ -33,7 +33,7 @@ __device__ __forceinline__ int xs_slot(int pc, int q, int row, int BM) {
 __device__ __forceinline__ float elu_hw1(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
 }  // namespace
 
-template <int TM, int TN, int EPI>
+template <int TM, int TN, int EPI, int NP>
 __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmDev p) {
   constexpr int BM = 32 * TM, BN = 32 * TN, NT = BN / 16;
   constexpr int XI = BM * 4 / 256;       // (row, q) pairs of the X chunk per thread
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmDev p) {
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc) wf[pc] = ws[((wn * TN + t) * 3 + pc) * 64 + lane];
 #pragma unroll
-      for (int mt = 0; mt < TM; ++mt) acc[t][mt] = mfma_b3(wf, xf[mt], acc[t][mt]);
+      for (int mt = 0; mt < TM; ++mt) acc[t][mt] = mfma_b3<NP>(wf, xf[mt], acc[t][mt]);
     }
   }
 
@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) void gemm_b3_kernel(GemmDev p) {
 // 128 x 128 tiles win once they make >= 2 workgroups per CU (ConvTranspose stages); below that the 64 x 64 tiles win although
 // they re-read more -- at M = 2048 (conv0, the transformer Linears) what counts is workgroups in flight per CU (5 fit), e.g.
 // conv0 188 -> 137 us, qkv 41 -> 34 us, fc1 48 -> 40 us; 128 x 64 only serves the narrow outputs (N < 128) of long tensors.
-template <int EPI>
-static int launch_b3_epi(const GemmDev& d, hipStream_t stream) {
+template <int EPI, int NP>
+static int launch_b3_epi_np(const GemmDev& d, hipStream_t stream) {
   auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
   GemmDev g = d;
   static const int env_taps = ST_KNOB_INT("SMOLTTS_B3_TAPS", 1);  // experiments (knobs builds only): 0 = K order
@@ -183,7 +183,7 @@ static int launch_b3_epi(const GemmDev& d, hipStream_t stream) {
   if (d.splitk_ws && d.N % 4 == 0 && blocks(64, 64) <= 512 && (d.K >> 5) >= 48 && 4L * d.M * d.N <= d.splitk_cap) {
     g.ksplit = 4;
     const dim3 grid = grid1d(64, 64);
-    hipLaunchKernelGGL((gemm_b3_kernel<2, 2, EPI>), grid, dim3(256), 0, stream, g);
+    hipLaunchKernelGGL((gemm_b3_kernel<2, 2, EPI, NP>), grid, dim3(256), 0, stream, g);
     ST_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3((unsigned)(((long)d.M * (d.N >> 2) + 255) / 256)), dim3(256), 0, stream, g);
     ST_CHECK_HIP(hipGetLastError());
@@ -192,16 +192,21 @@ static int launch_b3_epi(const GemmDev& d, hipStream_t stream) {
   static const int force = ST_KNOB_INT("SMOLTTS_B3_TILE", 0);  // experiments (knobs builds only): 44 | 42 | 22
   if (force == 44 || (force == 0 && blocks(128, 128) >= 512 && d.N >= 128)) {
     const dim3 grid = grid1d(128, 128);
-    hipLaunchKernelGGL((gemm_b3_kernel<4, 4, EPI>), grid, dim3(256), 0, stream, g);
+    hipLaunchKernelGGL((gemm_b3_kernel<4, 4, EPI, NP>), grid, dim3(256), 0, stream, g);
   } else if (force == 42 || (force == 0 && blocks(128, 64) >= 512 && d.N < 128)) {
     const dim3 grid = grid1d(128, 64);
-    hipLaunchKernelGGL((gemm_b3_kernel<4, 2, EPI>), grid, dim3(256), 0, stream, g);
+    hipLaunchKernelGGL((gemm_b3_kernel<4, 2, EPI, NP>), grid, dim3(256), 0, stream, g);
   } else {
     const dim3 grid = grid1d(64, 64);
-    hipLaunchKernelGGL((gemm_b3_kernel<2, 2, EPI>), grid, dim3(256), 0, stream, g);
+    hipLaunchKernelGGL((gemm_b3_kernel<2, 2, EPI, NP>), grid, dim3(256), 0, stream, g);
   }
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
+}
+
+template <int EPI>
+static int launch_b3_epi(const GemmDev& d, hipStream_t stream) {
+  return d.b3_products == 3 ? launch_b3_epi_np<EPI, 3>(d, stream) : launch_b3_epi_np<EPI, 6>(d, stream);
 }
 
 bool gemm_b3_applies(int M, int N, int K, int epilogue) {

@@ -40,6 +40,7 @@ struct GemmDev {
   int ksplit;                  // set by the launcher: K split over this many workgroups per tile (1 = no split)
   int taps, cpt;               // set by the launcher: conv windows (K = taps * ldx, overlapping rows): 32-k chunks are visited channel
                                // slice by channel slice, all taps of a slice back to back; cpt = chunks per tap.  taps = 1: in order
+  int b3_products;             // 3 = the bf16x3 kernels form three products per operand pair instead of six (mfma_b3<3>); anything else: six
   int xcd_cols;                // set by the launcher: 1 = the XCDs are dealt column blocks (W leaves memory once), 0 = row blocks (X does)
 };
 
@@ -168,9 +169,14 @@ __device__ __forceinline__ void split3x8(const float4 a, const float4 b, uint4& 
 // acc += W . x over one 32-k chunk with both operands split in three bf16 pieces: the six products whose weight is
 // >= 2^-16 of the leading one (dropped: mid*lo, lo*mid, lo*lo, each <= 2^-24 relative: below the rounding of the fp32
 // accumulation itself), smallest first.  Products of bf16 pieces are exact in the fp32 accumulator.
+// NP = 6 (default): fp32-grade.  NP = 3 (a session option, SMOLTTS_MIMI_OPT_PRODUCTS: DESIGN.md 4.7): only the products of weight
+// >= 2^-8 of the leading one (hi*hi, mid*hi, hi*mid); the dropped ones are each <= 2^-16 relative, the lo pieces are never loaded.
+template <int NP = 6>
 __device__ __forceinline__ f32x4 mfma_b3(const uint4 w[3], const uint4 x[3], f32x4 acc) {
+  static_assert(NP == 3 || NP == 6, "bf16x3 products: 3 or 6");
 #define ST_MF(WP, XP) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w[WP]), __builtin_bit_cast(bf16x8_t, x[XP]), acc, 0, 0, 0)
-  ST_MF(1, 1); ST_MF(2, 0); ST_MF(0, 2); ST_MF(1, 0); ST_MF(0, 1); ST_MF(0, 0);
+  if constexpr (NP == 6) { ST_MF(1, 1); ST_MF(2, 0); ST_MF(0, 2); }
+  ST_MF(1, 0); ST_MF(0, 1); ST_MF(0, 0);
 #undef ST_MF
   return acc;
 }

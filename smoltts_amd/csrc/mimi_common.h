@@ -14,6 +14,7 @@ struct MimiTransformerBufs {
   float* tws = nullptr;           // optional split-K workspace (4 x rows x 512 floats) for the fc2 GEMM of many-row calls
   char *kc3 = nullptr, *vc3 = nullptr;  // optional bf16x3 piece caches [n_layers][slots][8][ceil32(cache_len)] x 384 bytes (zero-filled once):
   size_t layer_stride3 = 0;             // the QKV GEMM writes them beside kc / vc, chunks of a multiple of 32 rows per slot attend over them
+  int b3_products = 6;                  // 3: the many-row kernels form three bf16x3 products per operand pair (SMOLTTS_MIMI_OPT_PRODUCTS)
 };
 
 // The 8-layer pre-LayerNorm block stack of codec/transformer.py:109-150 over `rows` rows (`rows_per_slot`
@@ -35,6 +36,7 @@ struct MimiResblockArgs {
   const void* w2; const float* b2;   // conv k3: W3 tiles of [C/2][3C], bias
   const void* w3; const float* b3;   // conv k1: W3 tiles of [C][C/2], bias
   float* out; int64_t o_bstride;
+  int b3_products;                   // 3 = three bf16x3 products per operand pair (SMOLTTS_MIMI_OPT_PRODUCTS); otherwise six
 };
 int launch_seanet_resblock(const MimiResblockArgs& a, hipStream_t st);
 
@@ -49,6 +51,7 @@ struct MimiLastStageArgs {
   const float* final_w; float final_b; // output conv k3 64 -> 1: fp32 [3][64]
   float* pcm; int64_t pcm_stride;
   const int* slot_pos;
+  int b3_products;                     // as MimiResblockArgs
 };
 int launch_seanet_last(const MimiLastStageArgs& a, hipStream_t st);
 

@@ -67,6 +67,7 @@ struct SmolttsMimiSession {
   float final_bias;  // bias of the output conv (read from the arena once, at session creation)
   int* pos_host;     // host mirror (deterministic: += 2 * frames per call for the slots decoded, 0 on reset)
   int parity;
+  int products;            // SMOLTTS_MIMI_OPT_PRODUCTS: 3 or 6 (0 = 6) bf16x3 products per operand pair in the matrix-core kernels
   int stateless_upsample;  // SMOLTTS_MIMI_OPT_STATELESS_UPSAMPLE: every call up-samples its frames with no carry (mimi.py:77)
 };
 
@@ -207,18 +208,20 @@ int run_mimi_transformer(const char* A, const SmolttsMimiLayerWeights* layers, i
       a.k_cache_dev = kc; a.v_cache_dev = vc;
       if (b.kc3) { a.k_cache3_dev = b.kc3 + l * b.layer_stride3; a.v_cache3_dev = b.vc3 + l * b.layer_stride3; }
       a.n_q_heads = HEADS; a.n_kv_heads = HEADS; a.cache_len = cache_len;
+      a.b3_products = b.b3_products;
       ST_TRY(launch_gemm(a, st));
     }
     static const bool rows3_off = ST_KNOB_INT("SMOLTTS_ROWS3", 1) == 0;  // experiments (knobs builds only)
     if (b.kc3 && Tt % 32 == 0 && !rows3_off)  // whole 32-row groups per slot: the bf16x3 kernel over the piece caches
       ST_TRY(launch_attention_rows3(b.tq, b.kc3 + l * b.layer_stride3, b.vc3 + l * b.layer_stride3, b.row_pos, b.row_slot, R, Tt, HEADS,
-                                    cache_len, window, b.ta, st));
+                                    cache_len, window, b.ta, st, b.b3_products));
     else
       ST_TRY(launch_attention(b.tq, kc, vc, b.row_pos, b.row_slot, R, HEADS, HEADS, cache_len, window, b.ta, nullptr, st));
     {
       SmolttsGemmArgs a = mimi_gemm_f32(A + lw.wo, b.ta, D, R, D, D, lw.wo3 ? A + lw.wo3 : nullptr);
       a.epilogue = SMOLTTS_EPI_SCALE_RESID; a.scale_dev = (const float*)(A + lw.ls1);
       a.resid_dev = b.tx; a.out_dev = b.tx; a.ldo = D;
+      a.b3_products = b.b3_products;
       ST_TRY(launch_gemm(a, st));
     }
     {
@@ -226,6 +229,7 @@ int run_mimi_transformer(const char* A, const SmolttsMimiLayerWeights* layers, i
       a.prologue = SMOLTTS_PRO_LAYERNORM; a.gamma_dev = (const float*)(A + lw.ln2_w); a.beta_dev = (const float*)(A + lw.ln2_b);
       a.eps = 1e-5f; a.ln_scratch_dev = b.tn;
       a.epilogue = SMOLTTS_EPI_GELU; a.out_dev = b.th; a.ldo = FF;
+      a.b3_products = b.b3_products;
       ST_TRY(launch_gemm(a, st));
     }
     {
@@ -239,6 +243,7 @@ int run_mimi_transformer(const char* A, const SmolttsMimiLayerWeights* layers, i
       } else {
         a.out_dev = last_out; a.ldo = D; a.o_bstride = last_bstride;
       }
+      a.b3_products = b.b3_products;
       ST_TRY(launch_gemm(a, st));
     }
   }
@@ -327,6 +332,11 @@ int smoltts_mimi_reset(SmolttsMimiSession* s, void* stream) {
 
 int smoltts_mimi_session_set_option(SmolttsMimiSession* s, int32_t option, int32_t value) {
   ST_REQUIRE(s, SMOLTTS_E_INVALID, "mimi_session_set_option: null session");
+  if (option == SMOLTTS_MIMI_OPT_PRODUCTS) {
+    ST_REQUIRE(value == 3 || value == 6, SMOLTTS_E_INVALID, "mimi_session_set_option: products %d (3 or 6)", value);
+    s->products = value;
+    return SMOLTTS_OK;
+  }
   ST_REQUIRE(option == SMOLTTS_MIMI_OPT_STATELESS_UPSAMPLE, SMOLTTS_E_INVALID, "mimi_session_set_option: unknown option %d", option);
   ST_REQUIRE(value == 0 || value == 1, SMOLTTS_E_INVALID, "mimi_session_set_option: value %d (0 or 1)", value);
   s->stateless_upsample = value;
@@ -403,7 +413,7 @@ static int decode_chunk_impl(SmolttsMimiSession* s, const int32_t* codes_dev, in
     MimiTransformerBufs tb{s->tx, s->tn, s->tq, s->ta, s->th, s->kc, s->vc, (size_t)s->B * HEADS * c.max_positions * 64,
                            s->row_pos, s->row_slot};
     tb.tws = s->tws;
-    tb.kc3 = s->kc3; tb.vc3 = s->vc3; tb.layer_stride3 = s->kv3_layer;
+    tb.kc3 = s->kc3; tb.vc3 = s->vc3; tb.layer_stride3 = s->kv3_layer; tb.b3_products = s->products == 3 ? 3 : 6;
     ST_TRY(run_mimi_transformer(A, m->w.layers, c.n_layers, (const float*)(A + m->w.rope), c.max_positions, c.window, tb, R, Tt,
                                 s->buf[0] + (size_t)BUF_HALO[0] * BUF_C[0], (int64_t)s->buf_bstride[0], st));
   }
@@ -424,7 +434,7 @@ static int decode_chunk_impl(SmolttsMimiSession* s, const int32_t* codes_dev, in
       a.wt = A + cv.w3; a.bt = (const float*)(A + cv.b);
       a.w2 = A + c2.w3; a.b2 = (const float*)(A + c2.b); a.w3 = A + c3.w3; a.b3 = (const float*)(A + c3.b);
       a.final_w = (const float*)(A + m->w.final_w); a.final_b = s->final_bias; a.pcm = pcm_dev; a.pcm_stride = pcm_stride;
-      a.slot_pos = s->pos_dev;
+      a.slot_pos = s->pos_dev; a.b3_products = s->products;
       ST_TRY(launch_seanet_last(a, st));
       break;
     }
@@ -437,6 +447,7 @@ static int decode_chunk_impl(SmolttsMimiSession* s, const int32_t* codes_dev, in
       a.x = s->buf[i] + (size_t)BUF_HALO[i] * BUF_C[i]; a.x_bstride = (int64_t)s->buf_bstride[i];
       a.w2 = A + cv.w3; a.b2 = (const float*)(A + cv.b); a.w3 = A + c1.w3; a.b3 = (const float*)(A + c1.b);
       a.out = s->buf[i + 2] + (size_t)BUF_HALO[i + 2] * BUF_C[i + 2]; a.o_bstride = (int64_t)s->buf_bstride[i + 2];
+      a.b3_products = s->products;
       ST_TRY(launch_seanet_resblock(a, st));
       i += 1;
       continue;
@@ -466,6 +477,7 @@ static int decode_chunk_impl(SmolttsMimiSession* s, const int32_t* codes_dev, in
       a.resid_dev = s->buf[i - 1] + (size_t)BUF_HALO[i - 1] * BUF_C[i - 1];
       a.ldr = BUF_C[i - 1]; a.r_bstride = (int64_t)s->buf_bstride[i - 1];
     }
+    a.b3_products = s->products;
     ST_TRY(launch_gemm(a, st));
   }
 

@@ -54,7 +54,7 @@ struct ResCfg {
   static_assert(K2C % GK2 == 0 && NT2 * GK2 * 3072 <= WB_BYTES && NT3 * GK3 * 3072 <= WB_BYTES, "weight groups");
 };
 
-template <int C, int RC, int NW>
+template <int C, int RC, int NW, int NP>
 __global__ __launch_bounds__(NW * 64) void resblock_kernel(ResDev p) {
   using K = ResCfg<C, RC, NW>;
   constexpr int NTHR = NW * 64;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(NW * 64) void resblock_kernel(ResDev p) {
             uint4 wf[3];
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) wf[pc] = wb[(((wc * CW + j) * K::GK2 + kcl) * 3 + pc) * 64 + lane];
-            acc[i][j] = mfma_b3(wf, xf, acc[i][j]);
+            acc[i][j] = mfma_b3<NP>(wf, xf, acc[i][j]);
           }
         }
       }
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(NW * 64) void resblock_kernel(ResDev p) {
             uint4 wf[3];
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) wf[pc] = wb[(((wc * CW + j) * K::GK3 + kcl) * 3 + pc) * 64 + lane];
-            acc[i][j] = mfma_b3(wf, xf, acc[i][j]);
+            acc[i][j] = mfma_b3<NP>(wf, xf, acc[i][j]);
           }
         }
       }
@@ -243,18 +243,18 @@ __global__ __launch_bounds__(NW * 64) void resblock_kernel(ResDev p) {
 
 }
 
-template <int C, int RC, int NW>
+template <int C, int RC, int NW, int NP>
 int launch_res(const ResDev& d, int batch, hipStream_t st) {
   using K = ResCfg<C, RC, NW>;
   static PerDevice attr;
   const int dev = PerDevice::current();
   if (!attr.done(dev)) {  // > 64 KB of dynamic LDS must be requested once per kernel and device
-    ST_CHECK_HIP(hipFuncSetAttribute((const void*)resblock_kernel<C, RC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS));
+    ST_CHECK_HIP(hipFuncSetAttribute((const void*)resblock_kernel<C, RC, NW, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS));
     attr.mark_done(dev);
   }
   const dim3 grid((d.T + K::RT - 1) / K::RT, batch);
   ST_REQUIRE(grid.y <= 65535, SMOLTTS_E_INVALID, "resblock: batch too large");
-  hipLaunchKernelGGL((resblock_kernel<C, RC, NW>), grid, dim3(NW * 64), K::LDS, st, d);
+  hipLaunchKernelGGL((resblock_kernel<C, RC, NW, NP>), grid, dim3(NW * 64), K::LDS, st, d);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
 }
@@ -265,7 +265,7 @@ int launch_seanet_resblock(const MimiResblockArgs& a, hipStream_t st) {
   ST_REQUIRE(a.x && a.w2 && a.b2 && a.w3 && a.b3 && a.out && a.T > 0 && a.batch > 0, SMOLTTS_E_INVALID, "resblock: null or empty argument");
   ResDev d{a.x, (long)a.x_bstride, a.T, (const char*)a.w2, a.b2, (const char*)a.w3, a.b3, a.out, (long)a.o_bstride};
   // (48- and 64-row tiles were measured: 460 / 367 us against 341 us -- one workgroup per CU hides less than two or three)
-  if (a.channels == 128) return launch_res<128, 32, 8>(d, a.batch, st);
+  if (a.channels == 128) return a.b3_products == 3 ? launch_res<128, 32, 8, 3>(d, a.batch, st) : launch_res<128, 32, 8, 6>(d, a.batch, st);
   set_error("resblock: no instance for %d channels", a.channels);
   return SMOLTTS_E_INVALID;
 }

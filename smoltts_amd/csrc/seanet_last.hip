@@ -79,6 +79,7 @@ __device__ unsigned long long g_last_stamps[16];
 #define ST_STAMP(I)
 #endif
 
+template <int NP>
 __global__ __launch_bounds__(512) void seanet_last_kernel(LastDev p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* ap = reinterpret_cast<uint4*>(smem);     // phase A: input pieces [piece][in chunk 4][q][RA]
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(512) void seanet_last_kernel(LastDev p) {
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) xf[pc] = ap[((pc * 4 + xc) * 4 + q) * RA + mt * 16 + r + tap];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) acc[mt][t] = mfma_b3(wq[kc & 1][t], xf, acc[mt][t]);
+        for (int t = 0; t < 2; ++t) acc[mt][t] = mfma_b3<NP>(wq[kc & 1][t], xf, acc[mt][t]);
       }
     }
 #endif
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(512) void seanet_last_kernel(LastDev p) {
           uint4 wf[3];
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc) wf[pc] = w2s[((nt * 6 + kc) * 3 + pc) * 64 + lane];
-          hb[nt] = mfma_b3(wf, xf, hb[nt]);
+          hb[nt] = mfma_b3<NP>(wf, xf, hb[nt]);
         }
       }
 #endif
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(512) void seanet_last_kernel(LastDev p) {
           uint4 wf[3];
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc) wf[pc] = w3s[((2 * wh + t) * 3 + pc) * 64 + lane];
-          y[mtl][t] = mfma_b3(wf, xf, (f32x4){0.f, 0.f, 0.f, 0.f});
+          y[mtl][t] = mfma_b3<NP>(wf, xf, (f32x4){0.f, 0.f, 0.f, 0.f});
         }
       }
       if (h + 1 < NHALF) ST_PHASE0(h + 1)
@@ -386,7 +387,8 @@ int launch_seanet_last(const MimiLastStageArgs& a, hipStream_t st) {
   static PerDevice attr;
   const int dev = PerDevice::current();
   if (!attr.done(dev)) {  // > 64 KB of dynamic LDS must be requested once per kernel and device
-    ST_CHECK_HIP(hipFuncSetAttribute((const void*)seanet_last_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    ST_CHECK_HIP(hipFuncSetAttribute((const void*)seanet_last_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    ST_CHECK_HIP(hipFuncSetAttribute((const void*)seanet_last_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
     attr.mark_done(dev);
   }
   const int tiles_per_slot = (a.T + S - 2) / (S - 1);
@@ -395,7 +397,8 @@ int launch_seanet_last(const MimiLastStageArgs& a, hipStream_t st) {
             a.final_w, a.final_b, a.pcm, (long)a.pcm_stride, a.slot_pos, tiles_per_slot, tiles_per_slot * a.batch};
   const int n_cu = device_cu_count();
   const dim3 grid(d.n_tiles < n_cu ? d.n_tiles : n_cu);  // persistent: the LDS footprint admits exactly one workgroup per CU
-  hipLaunchKernelGGL(seanet_last_kernel, grid, dim3(512), LDS_BYTES, st, d);
+  if (a.b3_products == 3) hipLaunchKernelGGL(seanet_last_kernel<3>, grid, dim3(512), LDS_BYTES, st, d);
+  else hipLaunchKernelGGL(seanet_last_kernel<6>, grid, dim3(512), LDS_BYTES, st, d);
   ST_CHECK_HIP(hipGetLastError());
   return SMOLTTS_OK;
 }

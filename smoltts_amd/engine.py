@@ -59,6 +59,7 @@ class GemmArgs(C.Structure):
         ("v_cache_dev", C.c_void_p), ("n_q_heads", C.c_int32), ("n_kv_heads", C.c_int32), ("cache_len", C.c_int32),
         ("w3_dev", C.c_void_p), ("splitk_ws_dev", C.c_void_p), ("splitk_ws_floats", C.c_int64),
         ("beta_dev", C.c_void_p), ("ln_scratch_dev", C.c_void_p), ("k_cache3_dev", C.c_void_p), ("v_cache3_dev", C.c_void_p),
+        ("b3_products", C.c_int32),
     ]
 
 
@@ -705,9 +706,13 @@ class MimiSession:
 
     SAMPLES_PER_FRAME = 1920
     OPT_STATELESS_UPSAMPLE = 1  # SMOLTTS_MIMI_OPT_STATELESS_UPSAMPLE
+    OPT_PRODUCTS = 2  # SMOLTTS_MIMI_OPT_PRODUCTS
 
-    def __init__(self, engine: MimiEngine, max_batch: int, max_chunk_frames: int = 8, stateless_upsample: bool = False):
-        """``stateless_upsample``: every decode call up-samples its frames with no tap overlap carried in from the call before --
+    def __init__(self, engine: MimiEngine, max_batch: int, max_chunk_frames: int = 8, stateless_upsample: bool = False,
+                 products: int = 6):
+        """``products`` = 3: the matrix-core kernels form three of the six bf16x3 products per operand pair (23 % faster chunks at a
+        PCM RMS error of 7e-7 instead of 1e-7 against the fp32 oracle: include/smoltts_hip.h, SMOLTTS_MIMI_OPT_PRODUCTS).
+        ``stateless_upsample``: every decode call up-samples its frames with no tap overlap carried in from the call before --
         the reference's ``decode_step`` (codec/mimi.py:73-77,101-104); off, chunked decode == batch decode."""
         self.engine, self.lib = engine, engine.lib
         self.B, self.chunk = max_batch, max_chunk_frames
@@ -721,6 +726,11 @@ class MimiSession:
         self.handle = h
         if stateless_upsample:
             self.set_stateless_upsample(True)
+        if products != 6:
+            self.set_products(products)
+
+    def set_products(self, n: int) -> None:
+        check(self.lib.smoltts_mimi_session_set_option(self.handle, self.OPT_PRODUCTS, int(n)), "smoltts_mimi_session_set_option")
 
     def set_stateless_upsample(self, on: bool) -> None:
         check(self.lib.smoltts_mimi_session_set_option(self.handle, self.OPT_STATELESS_UPSAMPLE, int(bool(on))),

@@ -40,7 +40,7 @@ def linear(x: torch.Tensor, w_tiles: torch.Tensor, N: int, *, w_fp32: bool = Fal
            elu_out: bool = False, raw_out: Optional[torch.Tensor] = None, raw_bstride: int = 0,
            w3: Optional[torch.Tensor] = None, splitk_ws: Optional[torch.Tensor] = None,
            beta: Optional[torch.Tensor] = None, ln_scratch: Optional[torch.Tensor] = None,
-           k_cache3: Optional[torch.Tensor] = None, v_cache3: Optional[torch.Tensor] = None) -> torch.Tensor:
+           k_cache3: Optional[torch.Tensor] = None, v_cache3: Optional[torch.Tensor] = None, b3_products: int = 6) -> torch.Tensor:
     """``w3`` (``pack_weight_w3`` of the same fp32 matrix): many-row calls run the bf16x3-split kernel (gemm_b3.hip).
     ``k_cache3`` / ``v_cache3`` (``kv3_cache``): EPI_QKV_ROPE also writes the K / V rows as bf16x3 pieces (``attention_rows3``)."""
     lib = E.load_library()
@@ -67,6 +67,7 @@ def linear(x: torch.Tensor, w_tiles: torch.Tensor, N: int, *, w_fp32: bool = Fal
     a.splitk_ws_dev, a.splitk_ws_floats = E.dptr(splitk_ws), (splitk_ws.numel() if splitk_ws is not None else 0)
     a.beta_dev, a.ln_scratch_dev = E.dptr(beta), E.dptr(ln_scratch)
     a.k_cache3_dev, a.v_cache3_dev = E.dptr(k_cache3), E.dptr(v_cache3)
+    a.b3_products = b3_products
     E.check(lib.smoltts_k_gemm(C.byref(a), E.current_stream_ptr()), "smoltts_k_gemm")
     return out
 

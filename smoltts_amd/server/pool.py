@@ -297,7 +297,7 @@ def scheduler_from_settings(settings):
 
     st = settings if isinstance(settings, ServerSettings) else ServerSettings(**settings)
     model = SmolTTS(checkpoint_dir=str(st.get_checkpoint_dir()), mimi_checkpoint=st.mimi_checkpoint, weight_format=st.weight_format)
-    return BatchScheduler(model, max_batch=st.max_batch, generation_settings=st.generation.to_settings())
+    return BatchScheduler(model, max_batch=st.max_batch, generation_settings=st.generation.to_settings(), codec_products=st.codec_products)
 
 
 def synthetic_scheduler(model: str = "tiny", seed: int = 21, mimi_seed: int = 5, max_batch: int = 4, frames_per_tick: int = 2,

@@ -60,7 +60,7 @@ class BatchScheduler:
 
     def __init__(self, tts, max_batch: int = 32, frames_per_tick: int = 4, generation_settings=None, max_prompt_rows: int = 4096,
                  prefill_chunk: Optional[int] = 128, overlap_stream_codec: bool = True, side_prefill: bool = True,
-                 side_prefill_min_active: Optional[int] = None):
+                 side_prefill_min_active: Optional[int] = None, codec_products: int = 6):
         import torch
 
         from ..config import GenerationSettings
@@ -69,6 +69,7 @@ class BatchScheduler:
 
         self.tts = tts
         self.B = max_batch
+        self.codec_products = codec_products  # SMOLTTS_MIMI_OPT_PRODUCTS of the codec sessions (6: fp32-grade)
         self.tick = frames_per_tick
         self.prefill_chunk = prefill_chunk  # columns per utterance per prefill call (None: whole prompts at once)
         # streaming requests: the codec pass of tick k is launched on a second stream by the host once it has seen tick k finish
@@ -199,7 +200,7 @@ class BatchScheduler:
             from ..engine import MimiSession
 
             if self._stream_codec is None:
-                self._stream_codec = MimiSession(self.tts.codec, max_batch=self.B, max_chunk_frames=max(self.tick, 1))
+                self._stream_codec = MimiSession(self.tts.codec, max_batch=self.B, max_chunk_frames=max(self.tick, 1), products=self.codec_products)
                 self._stream_codec.reset()
             if not self.overlap_stream_codec:  # (overlapped: the slot's stream restarts on the codec stream, right before the pass
                 self._stream_codec.reset_slots(streams)  # of the request's first tick and behind the previous tenant's last pass)
@@ -508,7 +509,7 @@ class BatchScheduler:
 
         torch = self._torch
         if self._batch_codec is None:
-            self._batch_codec = MimiSession(self.tts.codec, max_batch=self.CODEC_BATCH, max_chunk_frames=self.CODEC_CHUNK)
+            self._batch_codec = MimiSession(self.tts.codec, max_batch=self.CODEC_BATCH, max_chunk_frames=self.CODEC_CHUNK, products=self.codec_products)
             self._batch_codec.reset()
         sess = self._batch_codec
         m = occupied[-1] + 1  # the pass runs over slots 0..m-1; a hole among them decodes zeros that nobody reads

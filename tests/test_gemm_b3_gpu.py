@@ -53,6 +53,31 @@ def test_b3_store_matches_float64_and_the_fp32_kernel(E, ops, M, N, K):
     assert e_new < 2e-6 and e_new < 4 * e_old + 2e-7
 
 
+@pytest.mark.parametrize("M,N,K", [(2000, 640, 512), (2048, 1536, 512), (2048, 512, 2048), (4100, 256, 256)])
+def test_b3_three_products_are_the_2_to_minus_16_grade_form(E, ops, M, N, K):
+    """SmolttsGemmArgs.b3_products = 3 (SMOLTTS_MIMI_OPT_PRODUCTS): hi*hi + mid*hi + hi*mid only.  The dropped products are each
+    <= 2^-16 of the leading one, so the result equals float64 of the operands truncated to their hi + mid pieces up to those
+    terms: checked against float64 at 2e-5 relative (measured ~3e-6; six products: < 2e-6 as above) and against exactly that
+    truncated model at fp32-summation level.  Shapes: the generic kernel, the chunk-size Linears (conv_xs), split-K fc2, conv-size M."""
+    from smoltts_amd.packing import split3_bf16
+
+    g = torch.Generator().manual_seed(M + N + K + 3)
+    x = torch.randn(M, K, generator=g) * torch.logspace(-2, 2, K)[None]
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    ref = x.double() @ w.double().T + b.double()
+    w32, w3 = ops.pack_weight(w, fp32=True), ops.pack_weight_w3(w)
+    six = ops.linear(x.cuda(), w32, N, w_fp32=True, bias=b.cuda(), w3=w3).cpu()
+    three = ops.linear(x.cuda(), w32, N, w_fp32=True, bias=b.cuda(), w3=w3, b3_products=3).cpu()
+    xh, xm, _ = split3_bf16(x)
+    wh, wm, _ = split3_bf16(w)
+    model = (xh.double() @ wh.double().T + xm.double() @ wh.double().T + xh.double() @ wm.double().T) + b.double()
+    e3, e6, em = rel_err(three, ref), rel_err(six, ref), rel_err(three, model)
+    print(f"M={M} N={N} K={K}: rel err vs float64: three products {e3:.2e}, six {e6:.2e}; three vs its own model {em:.2e}")
+    assert not torch.equal(three, six)
+    assert e6 < 2e-6 and e6 < e3 < 2e-5 and em < 2e-6
+
+
 @pytest.mark.parametrize("M,N,K", [(2048, 512, 2048), (1000, 132, 1600), (256, 64, 1536)])
 def test_b3_split_k_is_deterministic_and_matches_float64(E, ops, M, N, K):
     """Long K over few tiles: four workgroups per tile + a fixed-order reduce pass (the Mimi transformer's fc2 shape first)."""

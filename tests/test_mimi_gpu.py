@@ -167,6 +167,34 @@ def test_decode_at_the_benchmark_shape_matches_oracle():
     eng.close()
 
 
+def test_three_product_codec_stays_far_inside_the_waveform_tolerance():
+    """SMOLTTS_MIMI_OPT_PRODUCTS = 3 (MimiSession(products=3)): the matrix-core kernels form three of the six bf16x3 products.
+    At the benchmark's shape (32 slots, chunk 32 + 1) and at small chunks the PCM stays within 5e-6 RMS of the fp32 oracle
+    (measured 6.5e-7 .. 8.3e-7; the contract's bar is 1e-4, the six-product default lands at ~1e-7), the option really changes the
+    arithmetic, can be switched back on a live session, and rejects other values."""
+    from oracle.mimi_oracle import MimiDecodeOracle
+    from smoltts_amd.codec.synthetic import synthetic_mimi_state
+    from smoltts_amd.engine import MimiEngine, MimiSession, SmolttsError
+
+    st = synthetic_mimi_state(seed=0)
+    orc = MimiDecodeOracle(st, window=0)
+    eng = MimiEngine(st, 8, window=0, max_positions=2 * 33 + 16)
+    for B, F, chunk in ((32, 33, 32), (3, 9, 4), (2, 20, 16)):
+        codes = torch.randint(0, 2048, (B, F, 8), generator=torch.Generator().manual_seed(B + F), dtype=torch.int32)
+        ref = orc.decode(codes.permute(0, 2, 1).long())[:, 0].numpy()
+        sess = MimiSession(eng, max_batch=B, max_chunk_frames=chunk, products=3)
+        three = sess.decode(codes.cuda()).cpu().numpy()
+        sess.set_products(6)
+        six = sess.decode(codes.cuda()).cpu().numpy()
+        with pytest.raises(SmolttsError):
+            sess.set_products(4)
+        sess.close()
+        e3, e6 = _rms(three - ref), _rms(six - ref)
+        print(f"B={B} F={F} chunk={chunk}: rms err three products {e3:.3e}, six {e6:.3e} (signal rms {_rms(ref):.3f})")
+        assert e6 <= 1e-6 and e6 < e3 <= 5e-6 and not np.array_equal(three, six)
+    eng.close()
+
+
 def test_hf_vectors_at_chunk_size(golden_dir):
     """The third-party vectors on the chunk-size kernels: tests/golden/mimi_hf_long.npz (30 frames, PCM from
     transformers.MimiModel.decode) replicated into 36 slots and decoded as ONE chunk of 30 frames -- 36 x 60 = 2160 rows
