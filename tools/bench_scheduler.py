@@ -42,7 +42,8 @@ def main():
         cfg.max_seq_len = int(os.environ.get("MAX_SEQ", cfg.max_seq_len))  # experiment: the session's KV stride
         tts = SmolTTS(state=synthetic_lm_state(cfg, seed=0), config=cfg, mimi_state=synthetic_mimi_state(seed=0))
         slots = int(os.environ.get("SLOTS", 32))
-        sched = BatchScheduler(tts, max_batch=slots, frames_per_tick=tick, generation_settings=GenerationSettings.greedy(max_new_tokens=400))
+        sched = BatchScheduler(tts, max_batch=slots, frames_per_tick=tick, generation_settings=GenerationSettings.greedy(max_new_tokens=400),
+                               codec_products=int(os.environ.get("CODEC_PRODUCTS", 6)))  # experiment: 3 = SMOLTTS_MIMI_OPT_PRODUCTS
     for _ in range(max(n_pool, 1) * 2):
         sched.synthesize("warm up", max_new_tokens=8)
     if streaming:
