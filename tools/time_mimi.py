@@ -1,6 +1,7 @@
 """Time of one Mimi chunk decode (default 32 slots x 32 frames = 1024 frames), HIP events, best of 3 streams.
 argv: [slots] [frames] [chunks per stream, default 7]: the best chunk (early in the stream) and the LAST chunk of the stream
-(the codec transformer attends to everything before it: window 0) are reported."""
+(the codec transformer attends to everything before it: window 0) are reported.  CODEC_PRODUCTS=3: SMOLTTS_MIMI_OPT_PRODUCTS."""
+import os
 import sys
 from pathlib import Path
 
@@ -14,7 +15,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 NCH = int(sys.argv[3]) if len(sys.argv) > 3 else 7
 eng = MimiEngine(synthetic_mimi_state(seed=0), 8, window=0, max_positions=2 * F * (NCH + 1) + 16)
-sess = MimiSession(eng, max_batch=B, max_chunk_frames=F)
+sess = MimiSession(eng, max_batch=B, max_chunk_frames=F, products=int(os.environ.get("CODEC_PRODUCTS", 6)))
 codes = torch.randint(0, 2048, (B, F * NCH, 8), dtype=torch.int32, device="cuda")
 pcm = torch.zeros(B, F * NCH * 1920, device="cuda")
 best, last = 1e9, 1e9
